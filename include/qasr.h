@@ -1,0 +1,185 @@
+/*
+ * qasr.h — C ABI of the MI355X integer-only ASR engine (libqasr_hip.so).
+ *
+ * The reference (kssteven418/Q-ASR) has no FFI: its boundary for this path is the Python
+ * nn.Module API (QuantAct / QuantConv1d / ConvASREncoder / ConvASRDecoder / EncDecCTCModel).
+ * This header is the native surface that sits directly under that API; each
+ * entry point names the reference interface it replaces.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every device buffer it passes;
+ * the engine owns its packed blob copy and scratch arena; every call returns an int status
+ * (QASR_OK == 0) and never throws; one engine per device, not thread-safe; work is enqueued on
+ * the caller's HIP stream (passed as void*) with no host synchronisation unless stated.
+ */
+#ifndef QASR_H
+#define QASR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QASR_OK 0
+#define QASR_ERR_ARG 1        /* bad argument / shape */
+#define QASR_ERR_BLOB 2       /* malformed packed model */
+#define QASR_ERR_HIP 3        /* HIP runtime error (see qasr_last_error) */
+#define QASR_ERR_UNSUPPORTED 4
+
+#define QASR_BLOB_MAGIC 0x52534151u /* "QASR" */
+#define QASR_BLOB_VERSION 3u
+
+/* ---- packed model ("blob") layout, produced by qasr/pack.py --------------------------------
+ * header | tensor table | op table | data (int8 weights, int32 biases, f64 requant multipliers,
+ * f32 scales).  All offsets are bytes from the start of the blob; data items are 16-B aligned. */
+typedef struct qasr_blob_header {
+  uint32_t magic, version;
+  uint32_t n_tensors, n_ops;
+  uint32_t feat_in;          /* mel bins entering the encoder */
+  uint32_t n_classes;        /* decoder outputs incl. blank */
+  uint32_t weight_bit, act_bit;
+  uint32_t n_domains, reserved;
+  uint64_t tensors_off, ops_off, domains_off, data_off, total_bytes;
+} qasr_blob_header;
+
+/* A time domain: every tensor of a domain has the same frame count T and per-utterance lengths.
+ * Domain 0 is the encoder input; a strided conv opens a new one with
+ * len' = (len + 2*padding - dilation*(kernel-1) - 1)/stride + 1   (MaskedConv1d.get_seq_len, jasper.py:170-173). */
+typedef struct qasr_domain_desc {
+  int32_t parent;              /* -1 for domain 0 */
+  uint32_t kernel, stride, dilation, padding;
+  uint32_t reserved[3];
+} qasr_domain_desc;
+
+/* dtype of an activation tensor stored as [B][C][Tp] (time contiguous, Tp = T rounded up to 64) */
+enum { QASR_DT_S8 = 0, QASR_DT_U8 = 1, QASR_DT_F32 = 2, QASR_DT_I32 = 3 };
+
+typedef struct qasr_tensor_desc {
+  uint32_t channels;
+  uint32_t dtype;
+  uint32_t domain;
+  uint32_t reserved;
+  int32_t producer;          /* op index that writes it, -1 for the network input */
+  int32_t last_use;          /* last op index that reads it */
+} qasr_tensor_desc;
+
+enum {
+  QASR_OP_QUANT_IN = 0,      /* QuantAct first layer: f32 features -> s8 (quant_modules.py:180-184) */
+  QASR_OP_DW = 1,            /* depthwise QuantConv1d + next QuantAct requant (jasper.py:569-583) */
+  QASR_OP_PW = 2,            /* 1x1 QuantConv1d (+ residual 1x1 convs + res_act) + next QuantAct requant */
+  QASR_OP_DENSE = 3,         /* dense k>1 QuantConv1d (Jasper) (+ residual panes) */
+  QASR_OP_LOGSOFTMAX = 4,    /* log_softmax + argmax over classes (conv_asr.py:275, ctc_models.py:405) */
+  QASR_OP_REQUANT = 5        /* stand-alone QuantAct requant of a stored s8 / i32 value (extra consumers) */
+};
+
+enum {
+  QASR_F_RELU = 1u << 0,        /* ReLU on the conv output before requantisation (jasper.py:661,687) */
+  QASR_F_MASK_OUT = 1u << 1,    /* write 0 for t >= len[b]: the consumer's MaskedConv1d mask (jasper.py:177-181) */
+  QASR_F_EXACT_Z = 1u << 2,     /* |acc| may reach 2^22: take z through the float32 round trip (quant_utils.py:187) */
+  QASR_F_LOGITS = 1u << 3,      /* decoder: emit f32 logits = fl32(fl32(acc)*s_b) as [B][T][C] */
+  QASR_F_RESADD = 1u << 4       /* res_act: q = clamp(rq(main) + rq(pane) ...) sequentially over panes */
+};
+
+#define QASR_MAX_PANES 12
+#define QASR_MAX_OUTS 3
+
+typedef struct qasr_pane {     /* one residual 1x1 conv feeding res_act (jasper.py:664-682) */
+  int32_t in;                  /* tensor id (u8, already requantised for this conv's QuantAct) */
+  uint32_t cin;
+  uint64_t w_off;              /* s8 [cout][cin_pad] */
+  uint64_t bias_off;           /* i32 [cout], includes the +128*sum(W) correction for u8 inputs */
+  uint64_t m_off;              /* f64 [cout]: s_b[c] / S  as m*2^-e (batch_frexp) */
+  uint64_t sb_off;             /* f32 [cout]: conv output scale (only read with QASR_F_EXACT_Z) */
+} qasr_pane;
+
+typedef struct qasr_out {      /* one consumer of the op's integer result */
+  int32_t tensor;              /* tensor id, -1 = unused */
+  int32_t lo, hi;              /* clamp range of the consumer's QuantAct */
+  uint32_t mode;               /* 0: scalar multiplier `m`; 1: per-channel table at m_off (f64[cout]);
+                                  2: identity copy of the integer result; 3: raw int32 accumulator */
+  uint64_t m_off;
+  double m;
+} qasr_out;
+
+typedef struct qasr_op_desc {
+  uint32_t kind, flags;
+  int32_t in;                  /* main input tensor */
+  uint32_t cin, cout, kernel, stride, dilation, padding;
+  uint32_t n_panes;
+  uint64_t w_off;              /* s8 weights: DW [c][kpad], PW [cout][cin_pad], DENSE [cout][k][cin_pad] */
+  uint64_t bias_off;           /* i32 [cout] (0 = none) */
+  uint64_t m_off;              /* RESADD: f64 [cout] multiplier of the main accumulator towards S */
+  uint64_t sb_off;             /* f32 [cout] conv output scale s_w[c]*s_x */
+  int32_t qlo, qhi;            /* RESADD clamp of res_act */
+  float in_inv_scale;          /* QUANT_IN: fl32(1/s) ; int32 range in qlo/qhi */
+  uint32_t reserved;
+  qasr_out outs[QASR_MAX_OUTS];
+  qasr_pane panes[QASR_MAX_PANES];
+} qasr_op_desc;
+
+/* ---- engine -------------------------------------------------------------------------------- */
+typedef struct qasr_engine qasr_engine;
+
+/* Build an engine from a packed model.  Replaces model construction + `qm.evaluate(model)` state:
+ * EncDecCTCModel.__init__ / encoder.bn_folding / calibrated QuantAct ranges
+ * (nemo/collections/asr/models/ctc_models.py:91-147, examples/asr/quantization/inference.py:105-136).
+ * `debug` != 0 keeps every intermediate tensor and int32 accumulator alive for qasr_engine_read_*. */
+int qasr_engine_create(const void* blob, size_t blob_bytes, int device, int debug, qasr_engine** out);
+void qasr_engine_destroy(qasr_engine* e);
+
+/* Encoder + decoder for one batch, replacing ConvASREncoder.forward + ConvASRDecoder.forward + argmax
+ * (nemo/collections/asr/modules/conv_asr.py:194-206,270-275; ctc_models.py:403-405).
+ * feats   device f32 [B][feat_in][T]   (the preprocessor's output, time contiguous)
+ * lens    device i32 [B]               valid frames per utterance
+ * logp    device f32 [B][T'][n_classes] log-probabilities (may be NULL)
+ * tokens  device i32 [B][T']           greedy argmax (may be NULL)
+ * lens_out device i32 [B]              encoded lengths (may be NULL)
+ * T' = qasr_engine_out_frames(e, T). */
+int qasr_engine_forward(qasr_engine* e, void* stream, const float* feats, const int32_t* lens, int B, int T,
+                        float* logp, int32_t* tokens, int32_t* lens_out);
+int qasr_engine_out_frames(const qasr_engine* e, int T);
+int qasr_engine_num_ops(const qasr_engine* e);
+
+/* Parity hooks (debug engines only; synchronise the stream).  acc: int32 [B][cout][T_out] = the
+ * value rint(conv_int) of QuantConv1d.int_conv (quant_modules.py:304) for op `op` (pane < 0: main conv). */
+int qasr_engine_read_acc(qasr_engine* e, int op, int pane, int32_t* host_out, size_t n_elems);
+int qasr_engine_read_tensor(qasr_engine* e, int tensor, void* host_out, size_t n_bytes, int* T_out, int* Tp_out);
+/* average device time (ms) per op kind over the last forward, measured with HIP events (debug engines) */
+int qasr_engine_last_op_ms(qasr_engine* e, float* ms_per_op, int n_ops);
+
+/* ---- stand-alone operators (same kernels the engine launches; device pointers) -------------- */
+
+/* AudioToMelSpectrogramPreprocessor.forward / FilterbankFeatures.forward
+ * (nemo/collections/asr/parts/features.py:334-397): pre-emphasis, STFT(512, hop 160, hann 320),
+ * power, mel filterbank, log, per-feature normalisation, mask, pad to a multiple of `pad_to`.
+ * audio f32 [B][S]; audio_lens i32 [B] (samples); fb f32 [n_mels][257]; window f32 [320];
+ * feats f32 [B][n_mels][T_pad]; feat_lens i32 [B].  T_pad = qasr_frontend_frames(S, pad_to). */
+int qasr_frontend_mel(void* stream, const float* audio, const int32_t* audio_lens, int B, int S,
+                      const float* fb, const float* window, int n_mels, float preemph, int pad_to,
+                      float* feats, int32_t* feat_lens, void* workspace, size_t workspace_bytes);
+int qasr_frontend_frames(int S, int pad_to);
+size_t qasr_frontend_workspace_bytes(int B, int S, int n_mels);
+
+/* QuantConv1d.int_conv accumulator only (quant_modules.py:301-305) for a 1x1 conv:
+ * x i8 [B][cin][Tp] (x_unsigned: bytes are u8), w s8 [cout][cin_pad], bias i32 [cout] or NULL,
+ * acc i32 [B][cout][Tp].  T valid columns. */
+int qasr_pw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, const int32_t* bias,
+                     int B, int cin, int cin_pad, int cout, int T, int Tp, int32_t* acc);
+/* depthwise int_conv accumulator: w s8 [c][kpad]; acc i32 [B][c][Tp_out] */
+int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, int B, int c, int kernel,
+                     int kpad, int stride, int dilation, int padding, int T, int Tp, int T_out, int Tp_out,
+                     int32_t* acc);
+/* fixedpoint_mul.forward for one operand (quant_utils.py:187-198,213): q = clamp(rint(acc*m[c]), lo, hi)
+ * with m[c] = mantissa*2^-e as f64; exact_z selects the float32 round trip through sb[c]. */
+int qasr_requant(void* stream, const int32_t* acc, const double* m, const float* sb, int exact_z, int relu,
+                 int B, int c, int Tp, int lo, int hi, int8_t* out);
+
+const char* qasr_last_error(void);
+const char* qasr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QASR_H */

@@ -1,0 +1,523 @@
+// Host runtime of the integer-only ASR engine: blob parsing, static buffer arena, launch plan, C ABI.
+// One engine per device; all work is enqueued on the caller's stream; no host synchronisation on the
+// forward path (parity hooks excepted).  See include/qasr.h for the contract.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "qasr_internal.h"
+
+using namespace qasr;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x)                                                                          \
+  do {                                                                                     \
+    hipError_t _e = (x);                                                                   \
+    if (_e != hipSuccess) return fail(QASR_ERR_HIP, "%s: %s", #x, hipGetErrorString(_e)); \
+  } while (0)
+
+static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+static inline size_t dt_size(uint32_t dt) { return (dt == QASR_DT_F32 || dt == QASR_DT_I32) ? 4 : 1; }
+
+struct TensorRT {
+  qasr_tensor_desc d;
+  int T = 0, Tp = 0;
+  size_t bytes = 0;
+  void* ptr = nullptr;
+  int slot = -1;
+};
+
+struct qasr_engine {
+  int device = 0;
+  bool debug = false;
+  std::vector<uint8_t> blob;           // host copy
+  uint8_t* dblob = nullptr;            // device copy
+  qasr_blob_header h{};
+  const qasr_tensor_desc* tdesc = nullptr;
+  const qasr_op_desc* ops = nullptr;
+  const qasr_domain_desc* doms = nullptr;
+  // shape plan
+  int B = 0, T0 = 0;
+  std::vector<int> domT;
+  std::vector<TensorRT> tens;
+  std::vector<void*> slots;            // owned device buffers
+  std::vector<size_t> slot_bytes;
+  int32_t* lens_all = nullptr;
+  std::vector<std::vector<int32_t*>> acc_dbg;   // [op][1 + pane]
+  std::vector<hipEvent_t> ev;          // debug timing: n_ops + 1 events
+  bool timed = false;
+};
+
+template <class T>
+static const T* dev_at(const qasr_engine* e, uint64_t off) {
+  return off ? reinterpret_cast<const T*>(e->dblob + e->h.data_off + off) : nullptr;
+}
+
+static int conv_out_len(int len, const qasr_domain_desc& d) {
+  int num = len + 2 * (int)d.padding - (int)d.dilation * ((int)d.kernel - 1) - 1;
+  int q = num >= 0 ? num / (int)d.stride : -((-num + (int)d.stride - 1) / (int)d.stride);
+  return q + 1;
+}
+
+static void free_plan(qasr_engine* e) {
+  for (void* p : e->slots) (void)hipFree(p);
+  e->slots.clear();
+  e->slot_bytes.clear();
+  if (e->lens_all) (void)hipFree(e->lens_all);
+  e->lens_all = nullptr;
+  for (auto& v : e->acc_dbg)
+    for (auto p : v)
+      if (p) (void)hipFree(p);
+  e->acc_dbg.clear();
+  e->tens.clear();
+  e->B = e->T0 = 0;
+}
+
+static int build_plan(qasr_engine* e, int B, int T0) {
+  free_plan(e);
+  const auto& h = e->h;
+  e->domT.assign(h.n_domains, 0);
+  e->domT[0] = T0;
+  for (uint32_t d = 1; d < h.n_domains; ++d) e->domT[d] = conv_out_len(e->domT[e->doms[d].parent], e->doms[d]);
+  for (uint32_t d = 0; d < h.n_domains; ++d)
+    if (e->domT[d] <= 0) return fail(QASR_ERR_ARG, "input of %d frames is too short for domain %u", T0, d);
+  e->tens.resize(h.n_tensors);
+  for (uint32_t i = 0; i < h.n_tensors; ++i) {
+    TensorRT& t = e->tens[i];
+    t.d = e->tdesc[i];
+    t.T = e->domT[t.d.domain];
+    t.Tp = rup(t.T, 64);
+    // f32 logits are [B][T][C]; everything else [B][C][Tp]
+    t.bytes = (t.d.dtype == QASR_DT_F32) ? (size_t)B * t.T * t.d.channels * 4 : (size_t)B * t.d.channels * t.Tp * dt_size(t.d.dtype);
+    t.bytes = (t.bytes + 255) / 256 * 256;
+  }
+  // greedy arena: a slot is reused once its tensor's last reader has been enqueued (stream order makes that safe)
+  std::vector<int> free_slots;
+  auto acquire = [&](TensorRT& t) -> int {
+    int best = -1;
+    if (!e->debug)
+      for (size_t k = 0; k < free_slots.size(); ++k) {
+        int s = free_slots[k];
+        if (e->slot_bytes[s] >= t.bytes && (best < 0 || e->slot_bytes[s] < e->slot_bytes[free_slots[best]])) best = (int)k;
+      }
+    int s;
+    if (best >= 0) {
+      s = free_slots[best];
+      free_slots.erase(free_slots.begin() + best);
+    } else {
+      void* p = nullptr;
+      if (hipMalloc(&p, t.bytes) != hipSuccess) return -1;
+      e->slots.push_back(p);
+      e->slot_bytes.push_back(t.bytes);
+      s = (int)e->slots.size() - 1;
+    }
+    t.slot = s;
+    t.ptr = e->slots[s];
+    return s;
+  };
+  for (uint32_t oi = 0; oi < h.n_ops; ++oi) {
+    for (uint32_t i = 1; i < h.n_tensors; ++i)      // tensor 0 is the caller's feature buffer
+      if (e->tens[i].d.producer == (int)oi && acquire(e->tens[i]) < 0) return fail(QASR_ERR_HIP, "hipMalloc failed (arena)");
+    for (uint32_t i = 1; i < h.n_tensors; ++i) {
+      TensorRT& t = e->tens[i];
+      bool dead_after = t.d.producer <= (int)oi && t.slot >= 0 && std::max(t.d.last_use, t.d.producer) == (int)oi;
+      if (dead_after && !e->debug) free_slots.push_back(t.slot);
+    }
+  }
+  HIPCHK(hipMalloc((void**)&e->lens_all, sizeof(int32_t) * h.n_domains * B));
+  if (e->debug) {
+    e->acc_dbg.resize(h.n_ops);
+    for (uint32_t oi = 0; oi < h.n_ops; ++oi) {
+      const qasr_op_desc& op = e->ops[oi];
+      if (op.kind != QASR_OP_DW && op.kind != QASR_OP_PW && op.kind != QASR_OP_DENSE) continue;
+      const TensorRT& o = e->tens[op.outs[0].tensor];
+      size_t n = (size_t)B * op.cout * rup(o.T, 64);
+      for (uint32_t k = 0; k < 1 + op.n_panes; ++k) {
+        int32_t* p = nullptr;
+        HIPCHK(hipMalloc((void**)&p, n * 4));
+        HIPCHK(hipMemset(p, 0, n * 4));
+        e->acc_dbg[oi].push_back(p);
+      }
+    }
+    if (e->ev.empty()) {
+      e->ev.resize(h.n_ops + 1);
+      for (auto& v : e->ev) HIPCHK(hipEventCreate(&v));
+    }
+  }
+  e->B = B;
+  e->T0 = T0;
+  return QASR_OK;
+}
+
+static void fill_out(const qasr_engine* e, const qasr_out& o, OutP& d) {
+  d.ptr = e->tens[o.tensor].ptr;
+  d.mtab = dev_at<double>(e, o.m_off);
+  d.m = o.m;
+  d.lo = o.lo;
+  d.hi = o.hi;
+  d.mode = (int)o.mode;
+  d.pad_ = 0;
+}
+
+static int fill_epi(const qasr_engine* e, int oi, const qasr_op_desc& op, EpiP& ep) {
+  memset(&ep, 0, sizeof ep);
+  int n = 0;
+  for (int j = 0; j < QASR_MAX_OUTS; ++j)
+    if (op.outs[j].tensor >= 0) fill_out(e, op.outs[j], ep.outs[n++]);
+  ep.n_outs = n;
+  ep.flags = op.flags;
+  ep.sb = dev_at<float>(e, op.sb_off);
+  ep.m_main = dev_at<double>(e, op.m_off);
+  const TensorRT& o0 = e->tens[op.outs[0].tensor];
+  ep.lens = e->lens_all + (size_t)o0.d.domain * e->B;
+  ep.acc_dbg = (e->debug && !e->acc_dbg[oi].empty()) ? e->acc_dbg[oi][0] : nullptr;
+  ep.qlo = op.qlo;
+  ep.qhi = op.qhi;
+  ep.T = o0.T;
+  ep.Tp = rup(o0.T, 64);
+  ep.cout = (int)op.cout;
+  ep.B = e->B;
+  if (op.flags & QASR_F_LOGITS) {
+    ep.logits = (float*)o0.ptr;
+    ep.n_outs = 0;
+  }
+  return QASR_OK;
+}
+
+static void fill_panes(const qasr_engine* e, int oi, const qasr_op_desc& op, PaneP* panes) {
+  for (uint32_t k = 0; k < op.n_panes; ++k) {
+    const qasr_pane& s = op.panes[k];
+    PaneP& d = panes[k];
+    const TensorRT& t = e->tens[s.in];
+    d.x = (const int8_t*)t.ptr;
+    d.w = dev_at<int8_t>(e, s.w_off);
+    d.bias = dev_at<int32_t>(e, s.bias_off);
+    d.m = dev_at<double>(e, s.m_off);
+    d.sb = dev_at<float>(e, s.sb_off);
+    d.acc_dbg = e->debug ? e->acc_dbg[oi][1 + k] : nullptr;
+    d.cin = (int)s.cin;
+    d.cin_pad = rup((int)s.cin, 64);
+    d.x_unsigned = t.d.dtype == QASR_DT_U8;
+    d.pad_ = 0;
+  }
+}
+
+extern "C" {
+
+const char* qasr_last_error(void) { return g_err.c_str(); }
+const char* qasr_version(void) { return "qasr-hip 0.1 (gfx950)"; }
+
+int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_engine** out) {
+  if (!blob || !out || n < sizeof(qasr_blob_header)) return fail(QASR_ERR_ARG, "null / short blob");
+  qasr_blob_header h;
+  memcpy(&h, blob, sizeof h);
+  if (h.magic != QASR_BLOB_MAGIC || h.version != QASR_BLOB_VERSION) return fail(QASR_ERR_BLOB, "bad magic / version");
+  if (h.total_bytes != n || h.reserved != sizeof(qasr_op_desc))
+    return fail(QASR_ERR_BLOB, "size mismatch: blob %zu vs header %llu, op record %u vs %zu", n,
+                (unsigned long long)h.total_bytes, h.reserved, sizeof(qasr_op_desc));
+  if (h.tensors_off + (uint64_t)h.n_tensors * sizeof(qasr_tensor_desc) > n ||
+      h.ops_off + (uint64_t)h.n_ops * sizeof(qasr_op_desc) > n ||
+      h.domains_off + (uint64_t)h.n_domains * sizeof(qasr_domain_desc) > n || h.data_off > n)
+    return fail(QASR_ERR_BLOB, "table offsets out of range");
+  HIPCHK(hipSetDevice(device));
+  qasr_engine* e = new qasr_engine();
+  e->device = device;
+  e->debug = debug != 0;
+  e->blob.assign((const uint8_t*)blob, (const uint8_t*)blob + n);
+  e->h = h;
+  e->tdesc = (const qasr_tensor_desc*)(e->blob.data() + h.tensors_off);
+  e->ops = (const qasr_op_desc*)(e->blob.data() + h.ops_off);
+  e->doms = (const qasr_domain_desc*)(e->blob.data() + h.domains_off);
+  for (uint32_t i = 0; i < h.n_ops; ++i) {
+    const qasr_op_desc& op = e->ops[i];
+    if (op.kind > QASR_OP_REQUANT || op.n_panes > QASR_MAX_PANES || op.in < 0 || op.in >= (int)h.n_tensors) {
+      delete e;
+      return fail(QASR_ERR_BLOB, "op %u malformed", i);
+    }
+  }
+  if (hipMalloc((void**)&e->dblob, n) != hipSuccess || hipMemcpy(e->dblob, blob, n, hipMemcpyHostToDevice) != hipSuccess) {
+    delete e;
+    return fail(QASR_ERR_HIP, "blob upload failed");
+  }
+  *out = e;
+  return QASR_OK;
+}
+
+void qasr_engine_destroy(qasr_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  free_plan(e);
+  for (auto v : e->ev) (void)hipEventDestroy(v);
+  if (e->dblob) (void)hipFree(e->dblob);
+  delete e;
+}
+
+int qasr_engine_num_ops(const qasr_engine* e) { return e ? (int)e->h.n_ops : -1; }
+
+int qasr_engine_out_frames(const qasr_engine* e, int T) {
+  if (!e) return -1;
+  std::vector<int> dT(e->h.n_domains);
+  dT[0] = T;
+  for (uint32_t d = 1; d < e->h.n_domains; ++d) dT[d] = conv_out_len(dT[e->doms[d].parent], e->doms[d]);
+  const qasr_op_desc& last = e->ops[e->h.n_ops - 1];
+  return dT[e->tdesc[last.in].domain];
+}
+
+int qasr_engine_forward(qasr_engine* e, void* stream, const float* feats, const int32_t* lens, int B, int T,
+                        float* logp, int32_t* tokens, int32_t* lens_out) {
+  if (!e || !feats || !lens || B <= 0 || T <= 0) return fail(QASR_ERR_ARG, "bad forward arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (B != e->B || T != e->T0) {
+    int rc = build_plan(e, B, T);
+    if (rc) return rc;
+  }
+  const auto& h = e->h;
+  e->tens[0].ptr = (void*)feats;
+  const qasr_domain_desc* ddoms = (const qasr_domain_desc*)(e->dblob + h.domains_off);
+  launch_lens(s, lens, e->lens_all, ddoms, (int)h.n_domains, B);
+  for (uint32_t oi = 0; oi < h.n_ops; ++oi) {
+    const qasr_op_desc& op = e->ops[oi];
+    if (e->debug) HIPCHK(hipEventRecord(e->ev[oi], s));
+    const TensorRT& tin = e->tens[op.in];
+    switch (op.kind) {
+      case QASR_OP_QUANT_IN: {
+        const TensorRT& to = e->tens[op.outs[0].tensor];
+        QuantInP p{};
+        p.x = (const float*)tin.ptr;
+        p.out = (int8_t*)to.ptr;
+        p.lens = e->lens_all + (size_t)to.d.domain * B;
+        p.inv_scale = op.in_inv_scale;
+        p.lo = op.qlo;
+        p.hi = op.qhi;
+        p.C = (int)op.cin;
+        p.T = tin.T;
+        p.Tp = to.Tp;
+        p.B = B;
+        launch_quant_in(s, p);
+        break;
+      }
+      case QASR_OP_DW: {
+        DwP p{};
+        p.x = (const int8_t*)tin.ptr;
+        p.w = dev_at<int8_t>(e, op.w_off);
+        p.bias = dev_at<int32_t>(e, op.bias_off);
+        p.C = (int)op.cin;
+        p.K = (int)op.kernel;
+        p.kpad = rup(p.K, 4);
+        p.stride = (int)op.stride;
+        p.dilation = (int)op.dilation;
+        p.padding = (int)op.padding;
+        p.T_in = tin.T;
+        p.Tp_in = tin.Tp;
+        p.x_unsigned = tin.d.dtype == QASR_DT_U8;
+        fill_epi(e, oi, op, p.e);
+        launch_dw(s, p);
+        break;
+      }
+      case QASR_OP_PW: {
+        PwP p{};
+        p.x = (const int8_t*)tin.ptr;
+        p.w = dev_at<int8_t>(e, op.w_off);
+        p.bias = dev_at<int32_t>(e, op.bias_off);
+        p.cin = (int)op.cin;
+        p.cin_pad = rup(p.cin, 64);
+        p.x_unsigned = tin.d.dtype == QASR_DT_U8;
+        p.n_panes = (int)op.n_panes;
+        fill_panes(e, oi, op, p.panes);
+        fill_epi(e, oi, op, p.e);
+        launch_pw(s, p);
+        break;
+      }
+      case QASR_OP_DENSE: {
+        DenseP p{};
+        p.x = (const int8_t*)tin.ptr;
+        p.w = dev_at<int8_t>(e, op.w_off);
+        p.bias = dev_at<int32_t>(e, op.bias_off);
+        p.cin = (int)op.cin;
+        p.cin_pad = rup(p.cin, 64);
+        p.K = (int)op.kernel;
+        p.stride = (int)op.stride;
+        p.dilation = (int)op.dilation;
+        p.padding = (int)op.padding;
+        p.T_in = tin.T;
+        p.Tp_in = tin.Tp;
+        p.x_unsigned = tin.d.dtype == QASR_DT_U8;
+        p.n_panes = (int)op.n_panes;
+        fill_panes(e, oi, op, p.panes);
+        fill_epi(e, oi, op, p.e);
+        launch_dense(s, p);
+        break;
+      }
+      case QASR_OP_REQUANT: {
+        const TensorRT& to = e->tens[op.outs[0].tensor];
+        RequantP p{};
+        p.in = tin.ptr;
+        p.in_is_i32 = tin.d.dtype == QASR_DT_I32;
+        fill_out(e, op.outs[0], p.out);
+        p.sb = dev_at<float>(e, op.sb_off);
+        p.lens = e->lens_all + (size_t)to.d.domain * B;
+        p.flags = op.flags & QASR_F_MASK_OUT;   // the stored value is already ReLU'd / round-tripped z
+        p.C = (int)op.cin;
+        p.T = to.T;
+        p.Tp = to.Tp;
+        p.B = B;
+        launch_requant(s, p);
+        break;
+      }
+      case QASR_OP_LOGSOFTMAX: {
+        launch_logsoftmax(s, (const float*)tin.ptr, logp, tokens, B * tin.T, (int)op.cin);
+        if (lens_out)
+          HIPCHK(hipMemcpyAsync(lens_out, e->lens_all + (size_t)tin.d.domain * B, sizeof(int32_t) * B,
+                                hipMemcpyDeviceToDevice, s));
+        break;
+      }
+      default:
+        return fail(QASR_ERR_UNSUPPORTED, "op kind %u", op.kind);
+    }
+  }
+  if (e->debug) {
+    HIPCHK(hipEventRecord(e->ev[h.n_ops], s));
+    e->timed = true;
+  }
+  HIPCHK(hipGetLastError());
+  return QASR_OK;
+}
+
+int qasr_engine_read_acc(qasr_engine* e, int op, int pane, int32_t* host_out, size_t n_elems) {
+  if (!e || !e->debug || op < 0 || op >= (int)e->h.n_ops || e->acc_dbg.empty()) return fail(QASR_ERR_ARG, "read_acc: not a debug engine / bad op");
+  const auto& v = e->acc_dbg[op];
+  int k = pane < 0 ? 0 : 1 + pane;
+  if (k >= (int)v.size()) return fail(QASR_ERR_ARG, "read_acc: op %d has no accumulator %d", op, k);
+  const qasr_op_desc& d = e->ops[op];
+  const TensorRT& o = e->tens[d.outs[0].tensor];
+  size_t n = (size_t)e->B * d.cout * rup(o.T, 64);
+  if (n_elems != n) return fail(QASR_ERR_ARG, "read_acc: expected %zu elements", n);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host_out, v[k], n * 4, hipMemcpyDeviceToHost));
+  return QASR_OK;
+}
+
+int qasr_engine_read_tensor(qasr_engine* e, int tensor, void* host_out, size_t n_bytes, int* T_out, int* Tp_out) {
+  if (!e || !e->debug || tensor <= 0 || tensor >= (int)e->tens.size()) return fail(QASR_ERR_ARG, "read_tensor: bad tensor / not debug");
+  const TensorRT& t = e->tens[tensor];
+  if (T_out) *T_out = t.T;
+  if (Tp_out) *Tp_out = t.Tp;
+  size_t want = (t.d.dtype == QASR_DT_F32) ? (size_t)e->B * t.T * t.d.channels * 4 : (size_t)e->B * t.d.channels * t.Tp * dt_size(t.d.dtype);
+  if (!host_out) return QASR_OK;
+  if (n_bytes != want) return fail(QASR_ERR_ARG, "read_tensor: expected %zu bytes", want);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host_out, t.ptr, want, hipMemcpyDeviceToHost));
+  return QASR_OK;
+}
+
+int qasr_engine_last_op_ms(qasr_engine* e, float* ms, int n_ops) {
+  if (!e || !e->debug || !e->timed || n_ops != (int)e->h.n_ops) return fail(QASR_ERR_ARG, "last_op_ms: no timed forward");
+  HIPCHK(hipEventSynchronize(e->ev[n_ops]));
+  for (int i = 0; i < n_ops; ++i) HIPCHK(hipEventElapsedTime(&ms[i], e->ev[i], e->ev[i + 1]));
+  return QASR_OK;
+}
+
+// ---------------------------------------------------------------------------------- stand-alone operators
+static void* g_zero = nullptr;
+static const size_t kZeroBytes = 1 << 20;
+static int zero_buf(void** p) {
+  if (!g_zero) {
+    HIPCHK(hipMalloc(&g_zero, kZeroBytes));
+    HIPCHK(hipMemset(g_zero, 0, kZeroBytes));
+  }
+  *p = g_zero;
+  return QASR_OK;
+}
+
+int qasr_pw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, const int32_t* bias, int B,
+                     int cin, int cin_pad, int cout, int T, int Tp, int32_t* acc) {
+  if (!x || !w || !acc || cin_pad % 64 || Tp % 64 || T > Tp) return fail(QASR_ERR_ARG, "pw_conv_acc: bad arguments");
+  void* z;
+  int rc = zero_buf(&z);
+  if (rc) return rc;
+  if ((size_t)rup(cout, 128) * 8 > kZeroBytes) return fail(QASR_ERR_ARG, "cout too large");
+  PwP p{};
+  p.x = x;
+  p.w = w;
+  p.bias = bias ? bias : (const int32_t*)z;
+  p.cin = cin;
+  p.cin_pad = cin_pad;
+  p.x_unsigned = x_unsigned;
+  p.e.sb = (const float*)z;
+  p.e.acc_dbg = acc;
+  p.e.T = T;
+  p.e.Tp = Tp;
+  p.e.cout = cout;
+  p.e.B = B;
+  p.e.lens = (const int32_t*)z;
+  launch_pw((hipStream_t)stream, p);
+  HIPCHK(hipGetLastError());
+  return QASR_OK;
+}
+
+int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, int B, int c, int kernel, int kpad,
+                     int stride, int dilation, int padding, int T, int Tp, int T_out, int Tp_out, int32_t* acc) {
+  if (!x || !w || !acc || kpad % 4 || kpad < kernel || Tp % 64 || Tp_out % 64) return fail(QASR_ERR_ARG, "dw_conv_acc: bad arguments");
+  void* z;
+  int rc = zero_buf(&z);
+  if (rc) return rc;
+  DwP p{};
+  p.x = x;
+  p.w = w;
+  p.bias = (const int32_t*)z;      // raw accumulator of the natural (unbiased) product is requested:
+  p.C = c;                          // callers pass x_unsigned = 0 with s8 data, or pre-biased data
+  p.K = kernel;
+  p.kpad = kpad;
+  p.stride = stride;
+  p.dilation = dilation;
+  p.padding = padding;
+  p.T_in = T;
+  p.Tp_in = Tp;
+  p.x_unsigned = x_unsigned;
+  p.e.sb = (const float*)z;
+  p.e.acc_dbg = acc;
+  p.e.T = T_out;
+  p.e.Tp = Tp_out;
+  p.e.cout = c;
+  p.e.B = B;
+  p.e.lens = (const int32_t*)z;
+  launch_dw((hipStream_t)stream, p);
+  HIPCHK(hipGetLastError());
+  return QASR_OK;
+}
+
+int qasr_requant(void* stream, const int32_t* acc, const double* m, const float* sb, int exact_z, int relu, int B, int c,
+                 int Tp, int lo, int hi, int8_t* out) {
+  if (!acc || !m || !out || (exact_z && !sb)) return fail(QASR_ERR_ARG, "requant: bad arguments");
+  RequantP p{};
+  p.in = acc;
+  p.in_is_i32 = 1;
+  p.out.ptr = out;
+  p.out.mtab = m;
+  p.out.lo = lo;
+  p.out.hi = hi;
+  p.out.mode = 1;
+  p.sb = sb;
+  p.flags = (exact_z ? QASR_F_EXACT_Z : 0) | (relu ? QASR_F_RELU : 0);
+  p.C = c;
+  p.T = Tp;
+  p.Tp = Tp;
+  p.B = B;
+  launch_requant((hipStream_t)stream, p);
+  HIPCHK(hipGetLastError());
+  return QASR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+// Mel front-end on gfx950: AudioToMelSpectrogramPreprocessor / FilterbankFeatures.forward
+// (nemo/collections/asr/parts/features.py:334-397, normalize_batch :53-67), float32 throughout.
+//   k_mel   : one wavefront per STFT frame — pre-emphasis + reflect padding folded into the framing load,
+//             hann(320) window centred in 512, 512-point radix-2 FFT in LDS, power, 64x257 mel projection,
+//             log(x + 2^-24); writes un-normalised log-mel [B][n_mels][T_pad]
+//   k_norm  : one wavefront per (utterance, mel bin) row — mean / unbiased std over the valid frames,
+//             (x - mean) / (std + 1e-5), zero beyond seq_len and in the pad_to padding
+// Float parity with the reference is tolerance based (FFT / reduction order): tests/test_gpu_frontend.py.
+#include "qasr_internal.h"
+
+namespace qasr {
+
+#define NFFT 512
+#define NBIN 257
+#define HOP 160
+#define WIN 320
+#define WOFF 96      /* (512 - 320) / 2: torch.stft centres the window inside n_fft */
+
+__device__ __forceinline__ int bitrev9(int x) { return (int)(__brev((unsigned)x) >> 23); }
+
+// y[i] of the pre-emphasised, reflect-padded signal (features.py:347-348; torch.stft center=True, pad_mode='reflect')
+__device__ __forceinline__ float sample(const float* x, int S, int i, float preemph) {
+  int ii = i < 0 ? -i : (i >= S ? 2 * (S - 1) - i : i);
+  ii = min(max(ii, 0), S - 1);
+  float v = x[ii];
+  if (ii > 0) v = v - __fmul_rn(preemph, x[ii - 1]);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) k_mel(const float* __restrict__ audio, int B, int S, const float* __restrict__ fb,
+                                             const float* __restrict__ window, int n_mels, float preemph, int n_frames,
+                                             int T_pad, float* __restrict__ out) {
+  __shared__ float re[4][NFFT], im[4][NFFT];
+  __shared__ float twc[NFFT / 2], tws[NFFT / 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // twiddles exp(-2*pi*i*k/512), k < 256
+  {
+    float s, c;
+    sincospif(-2.0f * (float)tid / (float)NFFT, &s, &c);
+    twc[tid] = c;
+    tws[tid] = s;
+  }
+  const int fidx = blockIdx.x * 4 + wave;            // frame index over B * n_frames
+  const bool ok = fidx < B * n_frames;
+  const int b = ok ? fidx / n_frames : 0, t = ok ? fidx - b * n_frames : 0;
+  const float* x = audio + (size_t)b * S;
+  // framing: sample j of frame t is ypad[160 t + j], ypad index 0 <-> signal index -256
+#pragma unroll
+  for (int i = 0; i < NFFT / 64; ++i) {
+    const int j = lane + 64 * i;
+    float v = 0.f;
+    if (j >= WOFF && j < WOFF + WIN) v = __fmul_rn(sample(x, S, HOP * t + j - NFFT / 2, preemph), window[j - WOFF]);
+    const int r = bitrev9(j);
+    re[wave][r] = v;
+    im[wave][r] = 0.f;
+  }
+  __syncthreads();
+  // in-place radix-2 DIT, 9 stages, 4 butterflies per lane per stage
+#pragma unroll 1
+  for (int s = 1; s <= 9; ++s) {
+    const int half = 1 << (s - 1), m = half << 1, tstep = NFFT / m;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = lane + 64 * q;
+      const int pos = i & (half - 1), grp = i >> (s - 1);
+      const int a = grp * m + pos, bb = a + half;
+      const float wr = twc[pos * tstep], wi = tws[pos * tstep];
+      const float xr = re[wave][bb], xi = im[wave][bb];
+      const float tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
+      const float ar = re[wave][a], ai = im[wave][a];
+      re[wave][a] = ar + tr;
+      im[wave][a] = ai + ti;
+      re[wave][bb] = ar - tr;
+      im[wave][bb] = ai - ti;
+    }
+    __syncthreads();
+  }
+  // power spectrum: the reference takes sqrt(re^2+im^2) and then pow(2) (features.py:356-360)
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int k = lane + 64 * i;
+    if (k < NBIN) {
+      const float r = re[wave][k], q = im[wave][k];
+      const float mag = sqrtf(r * r + q * q);
+      re[wave][k] = mag * mag;
+    }
+  }
+  __syncthreads();
+  // mel projection + log (features.py:363-368); lane = mel bin
+  for (int m0 = 0; m0 < n_mels; m0 += 64) {
+    const int m = m0 + lane;
+    if (m < n_mels && ok) {
+      const float* f = fb + (size_t)m * NBIN;
+      float acc = 0.f;
+      for (int k = 0; k < NBIN; ++k) acc = fmaf(f[k], re[wave][k], acc);
+      out[((size_t)b * n_mels + m) * T_pad + t] = logf(acc + 5.9604644775390625e-08f);   // 2^-24
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) k_norm(float* __restrict__ feats, const int32_t* __restrict__ audio_lens, int n_mels,
+                                             int n_frames, int T_pad, int32_t* __restrict__ feat_lens) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const int b = row / n_mels;
+  const int alen = audio_lens[b];
+  const int seq = (alen + HOP - 1) / HOP;              // get_seq_len: ceil(len / hop) (features.py:327-328)
+  if (lane == 0 && row % n_mels == 0) feat_lens[b] = seq;
+  float* x = feats + (size_t)row * T_pad;
+  const int n = min(seq, n_frames);
+  float s = 0.f;
+  for (int t = lane; t < n; t += 64) s += x[t];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)n;
+  float v = 0.f;
+  for (int t = lane; t < n; t += 64) {
+    const float d = x[t] - mean;
+    v += d * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const float sd = sqrtf(v / (float)(n - 1)) + 1e-5f;  // torch.std (unbiased) + CONSTANT (features.py:63-65)
+  for (int t = lane; t < T_pad; t += 64) x[t] = (t < n) ? (x[t] - mean) / sd : 0.f;
+}
+
+}  // namespace qasr
+
+extern "C" {
+
+int qasr_frontend_frames(int S, int pad_to) {
+  int n = 1 + S / HOP;
+  if (pad_to > 0 && n % pad_to) n += pad_to - n % pad_to;
+  return n;
+}
+
+size_t qasr_frontend_workspace_bytes(int, int, int) { return 0; }   // the feature buffer doubles as scratch
+
+int qasr_frontend_mel(void* stream, const float* audio, const int32_t* audio_lens, int B, int S, const float* fb,
+                      const float* window, int n_mels, float preemph, int pad_to, float* feats, int32_t* feat_lens,
+                      void*, size_t) {
+  if (!audio || !audio_lens || !fb || !window || !feats || !feat_lens || B <= 0 || S <= NFFT / 2 || n_mels <= 0)
+    return QASR_ERR_ARG;
+  const int n_frames = 1 + S / HOP;
+  const int T_pad = qasr_frontend_frames(S, pad_to);
+  hipStream_t s = (hipStream_t)stream;
+  const int frames = B * n_frames;
+  hipLaunchKernelGGL(qasr::k_mel, dim3((frames + 3) / 4), dim3(256), 0, s, audio, B, S, fb, window, n_mels, preemph,
+                     n_frames, T_pad, feats);
+  hipLaunchKernelGGL(qasr::k_norm, dim3(B * n_mels), dim3(64), 0, s, feats, audio_lens, n_mels, n_frames, T_pad,
+                     feat_lens);
+  return hipGetLastError() == hipSuccess ? QASR_OK : QASR_ERR_HIP;
+}
+}

@@ -1,0 +1,98 @@
+// Internal parameter blocks shared by the engine (qasr_engine.hip) and the kernels (qasr_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/qasr.h"
+
+namespace qasr {
+
+// One consumer of an op's integer result (device view of qasr_out).
+struct OutP {
+  void* ptr;            // i8 [B][C][Tp]  (mode 3: i32 [B][C][Tp])
+  const double* mtab;   // mode 1: per-channel multipliers
+  double m;             // mode 0: scalar multiplier
+  int lo, hi, mode;
+  int pad_;
+};
+
+struct PaneP {          // one residual 1x1 conv of a RESADD op
+  const int8_t* x;      // [B][cin][Tp]
+  const int8_t* w;      // [cout_pad][cin_pad]
+  const int32_t* bias;  // [cout_pad]
+  const double* m;      // [cout_pad]
+  const float* sb;      // [cout_pad]
+  int32_t* acc_dbg;     // optional [B][cout][Tp]
+  int cin, cin_pad, x_unsigned, pad_;
+};
+
+struct EpiP {
+  OutP outs[QASR_MAX_OUTS];
+  int n_outs;
+  unsigned flags;
+  const float* sb;        // conv output scale (EXACT_Z, LOGITS)
+  const double* m_main;   // RESADD
+  const int32_t* lens;    // [B] valid frames in the OUTPUT domain
+  int32_t* acc_dbg;       // optional i32 [B][cout][Tp]
+  float* logits;          // LOGITS: f32 [B][T][cout]
+  int qlo, qhi;
+  int T, Tp;              // output frames / row pitch
+  int cout, B;
+};
+
+struct PwP {              // 1x1 conv (+ residual panes)
+  const int8_t* x;        // [B][cin][Tp]
+  const int8_t* w;        // [cout_pad][cin_pad]
+  const int32_t* bias;    // [cout_pad]
+  int cin, cin_pad, x_unsigned, n_panes;
+  PaneP panes[QASR_MAX_PANES];
+  EpiP e;
+};
+
+struct DwP {              // depthwise conv
+  const int8_t* x;        // [B][C][Tp_in]
+  const int8_t* w;        // [C][kpad]
+  const int32_t* bias;    // [C_pad] (128*sum(w) for u8 inputs, else 0)
+  int C, K, kpad, stride, dilation, padding;
+  int T_in, Tp_in, x_unsigned, pad_;
+  EpiP e;
+};
+
+struct DenseP {           // dense k>1 conv as implicit GEMM (+ residual panes)
+  const int8_t* x;        // [B][cin][Tp_in]
+  const int8_t* w;        // [cout_pad][K][cin_pad]
+  const int32_t* bias;
+  int cin, cin_pad, K, stride, dilation, padding;
+  int T_in, Tp_in, x_unsigned, n_panes;
+  PaneP panes[QASR_MAX_PANES];
+  EpiP e;
+};
+
+struct QuantInP {
+  const float* x;         // [B][C][T]
+  int8_t* out;            // [B][C][Tp]
+  const int32_t* lens;
+  float inv_scale;
+  int lo, hi, C, T, Tp, B;
+};
+
+struct RequantP {         // stand-alone requant of a stored value
+  const void* in;         // i32 or s8 [B][C][Tp]
+  int in_is_i32;
+  OutP out;
+  const float* sb;
+  const int32_t* lens;
+  unsigned flags;
+  int C, T, Tp, B;
+};
+
+void launch_quant_in(hipStream_t s, const QuantInP& p);
+void launch_dw(hipStream_t s, const DwP& p);
+void launch_pw(hipStream_t s, const PwP& p);
+void launch_dense(hipStream_t s, const DenseP& p);
+void launch_requant(hipStream_t s, const RequantP& p);
+void launch_logsoftmax(hipStream_t s, const float* logits, float* logp, int32_t* tokens, int rows, int ncls);
+void launch_lens(hipStream_t s, const int32_t* lens_in, int32_t* lens_all, const qasr_domain_desc* doms,
+                 int n_domains, int B);
+
+}  // namespace qasr

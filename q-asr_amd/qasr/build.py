@@ -1,0 +1,35 @@
+"""Builds the native library in-tree: hipcc --offload-arch=gfx950 -> qasr/libqasr_hip.so
+(cross-compiles without a GPU; the .so travels to the GPU box with the snapshot)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), 'csrc')
+LIB = os.path.join(HERE, 'libqasr_hip.so')
+SOURCES = ['qasr_kernels.hip', 'qasr_engine.hip', 'qasr_frontend.hip']
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
+           [os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', 'qasr.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB] + srcs
+    if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_native(force='--force' in sys.argv, verbose=True))

