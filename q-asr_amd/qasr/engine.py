@@ -197,3 +197,24 @@ def requant(acc: torch.Tensor, M: torch.Tensor, lo, hi, sb=None, exact_z=False, 
     _check(lib.qasr_requant(_stream_ptr(), _ptr(a), _ptr(Md), _ptr(sbd), int(exact_z), int(relu), B, Cc, Tp, lo, hi,
                             _ptr(out)), 'qasr_requant')
     return out[:, :, :T]
+
+
+def frontend_mel(audio: torch.Tensor, lens: torch.Tensor, fb: torch.Tensor, window: torch.Tensor, preemph=0.97,
+                 pad_to=16):
+    """qasr_frontend_mel: audio f32 [B,S] (cuda), lens [B] samples, fb [n_mels,257], window [320]
+    -> (features f32 [B,n_mels,T_pad], feature lengths i32 [B])."""
+    lib = load_library()
+    assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 2
+    B, S = audio.shape
+    n_mels = fb.shape[0]
+    dev = audio.device
+    T_pad = lib.qasr_frontend_frames(S, pad_to)
+    feats = torch.empty(B, n_mels, T_pad, device=dev, dtype=torch.float32)
+    flens = torch.empty(B, device=dev, dtype=torch.int32)
+    a = audio.contiguous()
+    l32 = lens.to(device=dev, dtype=torch.int32).contiguous()
+    fbd = fb.to(device=dev, dtype=torch.float32).contiguous()
+    wd = window.to(device=dev, dtype=torch.float32).contiguous()
+    _check(lib.qasr_frontend_mel(_stream_ptr(), _ptr(a), _ptr(l32), B, S, _ptr(fbd), _ptr(wd), n_mels,
+                                 C.c_float(preemph), pad_to, _ptr(feats), _ptr(flens), None, 0), 'qasr_frontend_mel')
+    return feats, flens

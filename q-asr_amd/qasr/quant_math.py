@@ -18,16 +18,22 @@ def qrange(bits: int):
     return -n - 1, n
 
 
+# Scale arithmetic (divisions, frexp/ldexp) always runs on the host CPU on the tiny per-tensor / per-channel
+# vectors and only the element-wise multiply / round / clamp runs on the tensor's device: IEEE multiply is
+# identical everywhere, while GPU float division, pow and ldexp in PyTorch-ROCm are not guaranteed correctly
+# rounded - a 1-ulp scale difference would make host-calibrated integers differ from the packed engine's.
 def sym_scale(bits: int, lo: torch.Tensor, hi: torch.Tensor) -> torch.Tensor:
     n = 2 ** (bits - 1) - 1
-    m = torch.maximum(lo.float().abs(), hi.float().abs())
-    return torch.clamp(m, min=1e-8) / n
+    dev = lo.device
+    m = torch.maximum(lo.detach().float().cpu().abs(), hi.detach().float().cpu().abs())
+    return (torch.clamp(m, min=1e-8) / n).to(dev)
 
 
 def quantize(x: torch.Tensor, bits: int, scale: torch.Tensor) -> torch.Tensor:
     """Integers (as float32, like the reference) in [-n, n-1]."""
     n = 2 ** (bits - 1) - 1
-    return torch.clamp(torch.round(1.0 / scale * x), -n, n - 1)
+    inv = (1.0 / scale.detach().float().cpu()).to(x.device)
+    return torch.clamp(torch.round(inv * x), -n, n - 1)
 
 
 def ieee_sqrt(x: torch.Tensor) -> torch.Tensor:
@@ -39,8 +45,9 @@ def ieee_sqrt(x: torch.Tensor) -> torch.Tensor:
 
 
 def fold_bn(weight, bias, gamma, beta, mean, var, eps=1e-3):
-    std = ieee_sqrt(var + eps)
-    g = gamma / std
+    dev = weight.device
+    std = ieee_sqrt(var.detach().float().cpu() + eps)
+    g = (gamma.detach().float().cpu() / std).to(dev)
     w = weight * g.reshape(-1, 1, 1)
     b = torch.zeros_like(mean) if bias is None else bias
     return w, (b - mean) * g + beta
@@ -53,12 +60,12 @@ def weight_integers(weight: torch.Tensor, wbit: int):
     return quantize(weight, wbit, s_w.view(-1, 1, 1)), s_w
 
 
-def bias_integers(bias, s_w: torch.Tensor, s_x: torch.Tensor):
-    """-> (B_int float32 tensor or None, s_b [Cout]); 32-bit range, float32 evaluation."""
+def bias_integers(bias, s_w: torch.Tensor, s_x: torch.Tensor, bits: int = 32):
+    """-> (B_int float32 tensor or None, s_b [Cout]); `bits`-wide range, float32 evaluation."""
     s_b = s_w * s_x.reshape(-1)[0]
     if bias is None:
         return None, s_b
-    return quantize(bias, 32, s_b), s_b
+    return quantize(bias, bits, s_b), s_b
 
 
 def requant_multiplier(pre_sf: torch.Tensor, out_sf: torch.Tensor) -> torch.Tensor:
@@ -66,10 +73,11 @@ def requant_multiplier(pre_sf: torch.Tensor, out_sf: torch.Tensor) -> torch.Tens
 
     rint(f64(z) * M) equals fixedpoint_mul's rint(f64(z) * f64(m) / 2^e) bit for bit:
     scaling by a power of two commutes with the fp64 rounding of the product."""
-    r = pre_sf.double() / out_sf.float().double()
-    mant, ex = torch.frexp(r)
-    m = torch.floor(mant * float(2 ** 31) + 0.5)            # Decimal ROUND_HALF_UP on a positive value
-    return torch.ldexp(m, ex - 31)
+    import numpy as np
+    r = pre_sf.detach().float().cpu().double().numpy() / out_sf.detach().float().cpu().double().numpy()
+    mant, ex = np.frexp(r)
+    m = np.floor(mant * float(2 ** 31) + 0.5)               # Decimal ROUND_HALF_UP on a positive value
+    return torch.from_numpy(np.ldexp(m, ex - 31)).to(pre_sf.device)
 
 
 def requant(z: torch.Tensor, M: torch.Tensor, lo: int, hi: int) -> torch.Tensor:

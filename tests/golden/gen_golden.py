@@ -361,6 +361,45 @@ def gen_ops():
     print('ops.npz:', len(out), 'arrays')
 
 
+def gen_frontend():
+    """FilterbankFeatures.forward of the reference (features.py:334-397) on seeded audio, dither off.
+    librosa / torch_stft are absent: `librosa.filters.mel` is served by qasr.melbank (so the mel matrix
+    itself stays unpinned - real checkpoints carry it), the other imports are inert stubs."""
+    from qasr.melbank import mel_filterbank
+    lib = types.ModuleType('librosa')
+    lib.filters = types.ModuleType('librosa.filters')
+    lib.filters.mel = lambda sr, n_fft, n_mels=64, fmin=0, fmax=None: mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    lib.util = types.ModuleType('librosa.util')
+    lib.util.tiny = lambda x: np.finfo(np.float32).tiny
+    stubs = {'librosa': lib, 'librosa.filters': lib.filters, 'librosa.util': lib.util}
+    ts = types.ModuleType('torch_stft')
+    ts.STFT = type('STFT', (torch.nn.Module,), {})
+    stubs['torch_stft'] = ts
+    nu = types.ModuleType('nemo.utils')
+    nu.logging = types.SimpleNamespace(info=lambda *a, **k: None, debug=lambda *a, **k: None,
+                                       warning=lambda *a, **k: None)
+    stubs['nemo.utils'] = nu
+    for n, attr in (('nemo.collections.asr.parts.perturb', 'AudioAugmentor'),
+                    ('nemo.collections.asr.parts.segment', 'AudioSegment')):
+        m = types.ModuleType(n)
+        setattr(m, attr, type(attr, (), {}))
+        stubs[n] = m
+    sys.modules.update(stubs)
+    from nemo.collections.asr.parts.features import FilterbankFeatures
+    fe = FilterbankFeatures(sample_rate=16000, n_window_size=320, n_window_stride=160, window='hann',
+                            normalize='per_feature', n_fft=512, preemph=0.97, nfilt=64, dither=0.0, pad_to=16)
+    fe.eval()
+    audio = synth.make_audio(3, 24000, seed=9)
+    lens = np.array([24000, 17321, 8000], dtype=np.int64)
+    for i, n in enumerate(lens):
+        audio[i, n:] = 0
+    y, seq = fe(torch.from_numpy(audio.copy()), torch.from_numpy(lens))
+    np.savez_compressed(os.path.join(HERE, 'frontend.npz'), audio=audio, lens=lens, feats=y.numpy().astype(np.float32),
+                        seq_len=seq.numpy().astype(np.int64), fb=fe.fb[0].numpy().astype(np.float32),
+                        window=fe.window.numpy().astype(np.float32))
+    print('frontend.npz:', tuple(y.shape), seq.tolist())
+
+
 def gen_wer():
     """Known answers quoted from /root/reference/tests/collections/asr/test_asr_metrics.py:94-111."""
     cases = [dict(hyp=['cat'], ref=['cot'], wer=1.0),
@@ -378,6 +417,8 @@ if __name__ == '__main__':
     if not which or 'ops' in which:
         gen_ops()
         gen_wer()
+    if not which or 'frontend' in which:
+        gen_frontend()
     M = topology.MODELS
     if not which or 'mini' in which:
         run_net('net_miniq_w8a8', M['MiniQuartzNet'](), 1, 8, 8, None, 3, 96, (96, 71, 40), 3, 4, True)

@@ -1,0 +1,57 @@
+"""The C-ABI shared library loads and exports every symbol include/qasr.h declares; the packed-blob structs
+have the sizes pack.py serialises (checked with a gcc-compiled probe).  No compute calls: runs without a GPU."""
+import ctypes
+import os
+import re
+import struct
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, 'include', 'qasr.h')
+
+
+def _declared_symbols():
+    src = open(HDR).read()
+    return sorted(set(re.findall(r'\b(qasr_[a-z_0-9]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from qasr import build, engine
+    lib = ctypes.CDLL(build.build_native())
+    declared = _declared_symbols()
+    assert set(declared) == set(engine.SYMBOLS), set(declared) ^ set(engine.SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    lib.qasr_version.restype = ctypes.c_char_p
+    assert b'gfx950' in lib.qasr_version()
+    lib.qasr_frontend_frames.argtypes = [ctypes.c_int, ctypes.c_int]
+    assert lib.qasr_frontend_frames(80000, 16) == 512 and lib.qasr_frontend_frames(80000, 0) == 501
+
+
+def test_struct_sizes_match_packer(tmp_path):
+    probe = tmp_path / 'probe.c'
+    probe.write_text('#include <stdio.h>\n#include "qasr.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                     'sizeof(qasr_blob_header),sizeof(qasr_tensor_desc),sizeof(qasr_op_desc),sizeof(qasr_out),'
+                     'sizeof(qasr_pane),sizeof(qasr_domain_desc));return 0;}\n')
+    exe = tmp_path / 'probe'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(probe), '-o', str(exe)], check=True)
+    sizes = list(map(int, subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()))
+    assert sizes[0] == struct.calcsize('<10I5Q')
+    assert sizes[1] == struct.calcsize('<IIIIii')
+    assert sizes[3] == struct.calcsize('<iiiIQd') and sizes[4] == struct.calcsize('<iIQQQQ')
+    assert sizes[2] == struct.calcsize('<IIiIIIIIIIQQQQiifI') + 3 * sizes[3] + 12 * sizes[4]
+    assert sizes[5] == struct.calcsize('<iIIII3I')
+
+
+def test_engine_create_rejects_garbage_without_touching_gpu():
+    from qasr import build
+    lib = ctypes.CDLL(build.build_native())
+    lib.qasr_last_error.restype = ctypes.c_char_p
+    h = ctypes.c_void_p()
+    buf = ctypes.create_string_buffer(256)
+    rc = lib.qasr_engine_create(buf, ctypes.c_size_t(256), 0, 0, ctypes.byref(h))
+    assert rc == 2 and b'magic' in lib.qasr_last_error()      # QASR_ERR_BLOB before any HIP call
+    assert lib.qasr_engine_create(None, ctypes.c_size_t(0), 0, 0, ctypes.byref(h)) == 1

@@ -1,0 +1,206 @@
+"""Host-side drop-in surface (nemo.* façade, pack step) on CPU against the reference fixtures."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+import nemo.quantization.utils.quantize_model as qm
+from nemo.collections.asr.metrics.wer import WER, word_error_rate
+from nemo.collections.asr.models import EncDecCTCModel
+from nemo.quantization.utils.quant_modules import QuantAct, QuantConv1d
+from nemo.quantization.utils.quant_utils import batch_frexp, fixedpoint_mul
+from qasr import configs, pack, synth, topology
+
+torch.set_grad_enabled(False)
+
+
+def _mini(name):
+    return topology.mini_jasper() if 'minij' in name else topology.mini_quartznet()
+
+
+def _calibrated(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name + '.npz'))
+    meta = json.loads(str(d['meta']))
+    cfg = _mini(name)
+    m = EncDecCTCModel(configs.model_config(cfg))
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_state_dict(cfg, meta['seed']).items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected
+    # only the fork's extra buffers, the duplicated inner conv and the front-end buffers may be absent
+    for k in missing:
+        assert any(t in k for t in ('x_min', 'x_max', 'scaling_factor', '_integer', 'featurizer')), k
+    m.eval()
+    m.set_quant_bit(meta['wbit'], mode='weight')
+    m.set_quant_bit(meta['abit'], mode='act')
+    if meta['percentile'] is not None:
+        qm.set_percentile(m, meta['percentile'])
+    m.encoder.bn_folding()
+    qm.calibrate(m)
+    L = torch.tensor([meta['frames']] * meta['cal_batch'])
+    for c in synth.make_calibration(meta['ncal'], meta['cal_batch'], cfg.feat_in, meta['frames'], meta['seed']):
+        e, _, sf = m.encoder(audio_signal=torch.from_numpy(c), length=L)
+        m.decoder(encoder_output=e, encoder_output_scaling_factor=sf)
+    qm.evaluate(m)
+    qm.set_dynamic(m, False)
+    return d, meta, cfg, m
+
+
+@pytest.mark.parametrize('name', ['net_miniq_w8a8', 'net_miniq_w8a8_pct', 'net_miniq_w6a6', 'net_minij_w8a8'])
+def test_calibration_and_forward_match_reference(golden_dir, name):
+    """Same CLI sequence as inference.py:105-138 on the façade; ranges and tokens vs the reference's run."""
+    d, meta, cfg, m = _calibrated(golden_dir, name)
+    _, sd, amin, amax, wb, ab = m.export_pack_inputs()
+    assert (wb, ab) == (meta['wbit'], meta['abit'])
+    np.testing.assert_allclose(amin, d['act_min'], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(amax, d['act_max'], rtol=2e-6, atol=1e-7)
+    x = torch.from_numpy(synth.make_features(meta['batch'], cfg.feat_in, meta['frames'], meta['seed']))
+    e, l, sf = m.encoder(audio_signal=x, length=torch.tensor(meta['lengths']))
+    lp = m.decoder(encoder_output=e, encoder_output_scaling_factor=sf)
+    assert np.array_equal(l.numpy(), d['enc_len'])
+    if np.array_equal(amin, d['act_min']) and np.array_equal(amax, d['act_max']):
+        assert np.array_equal(lp.argmax(-1).numpy(), d['tokens'])
+        np.testing.assert_allclose(lp.numpy(), d['log_probs'], rtol=1e-4, atol=2e-5)
+    # the evaluate-mode model refuses to run the integer path on CPU: no silent fallback
+    assert m.engine_ready()
+    with pytest.raises(RuntimeError):
+        m(processed_signal=x, processed_signal_length=torch.tensor(meta['lengths']))
+
+
+def test_pack_blob_layout(golden_dir):
+    d, meta, cfg, m = _calibrated(golden_dir, 'net_miniq_w8a8')
+    blob, pm = pack.pack_model(*m.export_pack_inputs())
+    blob2, _ = pack.pack_model(cfg, synth.make_state_dict(cfg, meta['seed']), d['act_min'], d['act_max'], 8, 8)
+    if np.array_equal(m.export_pack_inputs()[2], d['act_min']) and np.array_equal(m.export_pack_inputs()[3], d['act_max']):
+        assert blob == blob2                      # live model and checkpoint+ranges pack to the same bytes
+    magic, version, n_t, n_ops, feat, ncls, wb, ab, ndom, opsz = struct.unpack_from('<10I', blob, 0)
+    assert magic == 0x52534151 and feat == cfg.feat_in and ncls == 29 and (wb, ab) == (8, 8)
+    assert n_ops == pm['n_ops'] and len(pm['sites']) == meta['nconv']
+
+
+def test_engine_path_fails_loudly_without_gpu(golden_dir):
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from qasr import engine
+    d = np.load(os.path.join(golden_dir, 'net_miniq_w8a8.npz'))
+    cfg = topology.mini_quartznet()
+    blob, _ = pack.pack_model(cfg, synth.make_state_dict(cfg, 1), d['act_min'], d['act_max'], 8, 8)
+    with pytest.raises(engine.QasrError):
+        engine.Engine(blob, 0)
+
+
+def test_quant_modes_and_switches():
+    m = EncDecCTCModel(configs.model_config(topology.mini_quartznet()))
+    acts = [a for a in m.modules() if isinstance(a, QuantAct)]
+    convs = [c for c in m.modules() if isinstance(c, QuantConv1d)]
+    assert all(a.quant_mode == 'symmetric' for a in acts)        # forced by the model (ctc_models.py:103-107)
+    qm.calibrate(m)
+    assert all(a.running_stat for a in acts) and all(c.fix_bn for c in convs)
+    qm.train(m)
+    assert all(a.running_stat for a in acts) and not any(c.fix_bn for c in convs)
+    qm.evaluate(m)
+    assert not any(a.running_stat for a in acts) and all(c.fix_bn for c in convs)
+    qm.set_percentile(m, 99.9)
+    assert all(a.percentile == 99.9 for a in acts)
+    qm.set_dynamic(m, True)
+    assert all(a.dynamic for a in acts)
+    m.set_quant_bit(6, mode='act')
+    asym = [mc for mc in m._masked_convs() if mc.asymmetric]
+    assert asym and all(mc.act.activation_bit == 7 for mc in asym)
+    assert all(b.res_act.activation_bit == 6 for b in m.encoder.encoder_layers)
+    m.set_quant_mode('none')
+    x = torch.randn(2, 16, 64)
+    out = m.encoder(audio_signal=x, length=torch.tensor([64, 50]))
+    assert out[0].shape == (2, 64, 32)
+
+
+def test_dynamic_mode_cpu_plumbing():
+    """BASELINE config 1: --dynamic, batch 1, CPU: per-batch min/max, no calibration."""
+    m = EncDecCTCModel(configs.model_config(topology.mini_quartznet()))
+    m.eval()
+    m.encoder.bn_folding()
+    qm.evaluate(m)
+    qm.set_dynamic(m, True)
+    assert not m.engine_ready()
+    x = torch.from_numpy(synth.make_features(1, 16, 96, 3))
+    lp, el, tok = m(processed_signal=x, processed_signal_length=torch.tensor([96]))
+    assert lp.shape == (1, 48, 29) and tok.shape == (1, 48) and int(el[0]) == 48
+    assert torch.isfinite(lp).all()
+
+
+def test_batch_frexp_and_fixedpoint(golden_dir):
+    d = np.load(os.path.join(golden_dir, 'ops.npz'))
+    m, e = batch_frexp(torch.from_numpy(d['frexp_in']).view(1, -1, 1))
+    assert np.array_equal(m.view(-1).numpy().astype(np.int64), d['frexp_m'])
+    assert np.array_equal(e.view(-1).numpy(), d['frexp_e'])
+    for tag, bits in (('requant8', 8), ('requant9', 9), ('requant_big', 8), ('res', 8), ('res_sat', 8)):
+        sf = torch.from_numpy(d[tag + '_sf'])
+        idn = torch.from_numpy(d[tag + '_id']) if tag + '_id' in d else None
+        idsf = torch.from_numpy(d[tag + '_id_sf']) if idn is not None else None
+        q = fixedpoint_mul.apply(torch.from_numpy(d[tag + '_x']), torch.from_numpy(d[tag + '_pre_sf']), bits,
+                                 'symmetric', sf, idn, idsf)
+        assert np.array_equal(q.numpy().astype(np.int32), d[tag + '_q']), tag
+
+
+def test_quant_act_module_against_reference(golden_dir):
+    d = np.load(os.path.join(golden_dir, 'ops.npz'))
+    for tag, bits in (('first8', 8), ('first6', 6), ('requant7', 7)):
+        a = QuantAct(bits, quant_mode='symmetric')
+        a.fix()
+        a.x_min = torch.tensor([d[tag + '_range'][0]])
+        a.x_max = torch.tensor([d[tag + '_range'][1]])
+        pre = torch.from_numpy(d[tag + '_pre_sf']) if tag + '_pre_sf' in d else None
+        y, sf = a(torch.from_numpy(d[tag + '_x']), pre)
+        assert np.array_equal(sf.reshape(-1).numpy(), d[tag + '_sf'])
+        assert np.array_equal(y.numpy(), d[tag + '_y'])
+
+
+def test_frontend_host_matches_reference(golden_dir):
+    d = np.load(os.path.join(golden_dir, 'frontend.npz'))
+    m = EncDecCTCModel(configs.model_config('QuartzNet15x5Base-En'))
+    f = m.preprocessor.featurizer
+    f.dither = 0.0
+    assert np.allclose(f.fb[0].numpy(), d['fb']) and np.allclose(f.window.numpy(), d['window'])
+    y, seq = m.preprocessor(input_signal=torch.from_numpy(d['audio']), length=torch.from_numpy(d['lens']))
+    assert np.array_equal(seq.numpy(), d['seq_len'])
+    np.testing.assert_allclose(y.numpy(), d['feats'], rtol=0, atol=2e-4)
+
+
+def test_wer_known_answers_and_decode(golden_dir):
+    for c in json.load(open(os.path.join(golden_dir, 'wer.json'))):
+        assert abs(word_error_rate(c['hyp'], c['ref']) - c['wer']) < 1e-12
+    with pytest.raises(ValueError):
+        word_error_rate(['a'], ['a', 'b'])
+    vocab = topology.VOCABULARY
+    w = WER(vocabulary=vocab)
+    blank = len(vocab)
+    toks = torch.tensor([[3, 3, blank, 3, 1, 1, blank, blank, 20], [blank] * 9])
+    assert w.ctc_decoder_predictions_tensor(toks) == ['ccat', '']
+    # randomized cross-check of the metric against the function (mirrors test_asr_metrics.py:114-135)
+    import random
+    rnd = random.Random(0)
+    for _ in range(32):
+        s1 = ''.join(rnd.choice(''.join(vocab)) for _ in range(rnd.randint(1, 80)))
+        s2 = ''.join(rnd.choice(''.join(vocab)) for _ in range(rnd.randint(1, 80)))
+        if not s2.strip():
+            continue
+        w.reset()
+        enc = lambda s: torch.tensor([[vocab.index(c) for c in s]])
+        pred = []
+        for c in s1:                                     # CTC-expand so repeats survive the collapse
+            pred += [vocab.index(c), blank]
+        w.update(torch.tensor([pred]), enc(s2), torch.tensor([len(s2)]))
+        assert abs(float(w.compute()[0]) - word_error_rate([s1], [s2])) < 1e-6
+
+
+def test_nemo_archive_round_trip(tmp_path):
+    m = EncDecCTCModel.from_synthetic('MiniQuartzNet', seed=4) if 'MiniQuartzNet' in topology.MODELS else None
+    path = str(tmp_path / 'mini.nemo')
+    m.save_to(path)
+    m2 = EncDecCTCModel.restore_from(path)
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    with pytest.raises(FileNotFoundError):
+        EncDecCTCModel.from_pretrained('QuartzNet15x5Base-En')
