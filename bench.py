@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RTFx of the quantised hot path (BASELINE.json config 2).
+
+One "step" = one pass of the hot path over one batch resident in HBM:
+    synthetic 16 kHz audio [32, 80000] (5 s each -> 500 valid mel frames)
+    -> HIP mel front-end -> integer QuartzNet15x5 encoder (w8a8, percentile 99.996 calibration)
+    -> CTC decoder -> log-softmax + greedy argmax tokens            (all in libqasr_hip.so)
+With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank runs its own 32-utterance
+shard (weak scaling); rank 0 calibrates + packs the model and broadcasts the packed int weights over RCCL,
+and each step ends with an RCCL gather of the greedy tokens to rank 0.
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the launch stream (each op
+replayed 20x between one event pair) for the dominant kernel class, the int8-MFMA pointwise GEMM k_pw; `cpu_baseline`
+times the reference's fake-quant CPU op sequence (oracle/fakequant_torch.py) on the host cores (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, 'q-asr_amd'), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_INT8_OPS = 256 * 4 * 2048 * 2.4e9       # 256 CUs x 4 SIMDs x 1024 MAC/clk (v_mfma_i32_32x32x32_i8) x 2.4 GHz
+PEAK_HBM = 8.0e12
+MODEL = 'QuartzNet15x5Base-En'
+BATCH, SAMPLES, FRAMES = 32, 80000, 500
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    print(f'[bench {time.time() - _T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU share of this process: min(affinity, cgroup quota); os.cpu_count() reports the whole host."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def algorithmic_work(cfg, B, T_out):
+    """Ops (2 per MAC) per forward by kernel class, from the topology (273.4 GOP MFMA-class,
+    28.2 GOP depthwise at B=32, T=500->250) and the minimal int8 activation bytes of the depthwise class."""
+    from qasr import topology
+    mfma = dw = dw_bytes = 0
+    for sites in topology.conv_plan(cfg):
+        for s in sites:
+            macs = B * T_out * s.cout * (s.cin // s.groups) * s.kernel
+            if s.role == 'dw':
+                dw += 2 * macs
+                dw_bytes += B * s.cout * T_out * (2 if s.stride == 1 else 3)
+            else:
+                mfma += 2 * macs
+    mfma += 2 * B * T_out * cfg.blocks[-1].filters * (cfg.num_classes + 1)
+    return mfma, dw, dw_bytes
+
+
+def build_model(device):
+    """Random-init QuartzNet15x5 (no network for checkpoints), calibrated exactly like inference.py does."""
+    import nemo.quantization.utils.quantize_model as qm
+    from nemo.collections.asr.models import EncDecCTCModel
+    from qasr import pack, synth
+    torch.set_grad_enabled(False)
+    m = EncDecCTCModel.from_synthetic(MODEL, seed=0).to(device)
+    m.eval()
+    m.set_quant_bit(8, mode='weight')
+    m.set_quant_bit(8, mode='act')
+    qm.set_percentile(m, 99.996)
+    m.encoder.bn_folding()
+    qm.calibrate(m)
+    log('model built; calibrating 2 x [8,64,500] (host PyTorch-ROCm)')
+    length = torch.tensor([FRAMES] * 8, device=device)
+    for c in synth.make_calibration(2, 8, 64, FRAMES, seed=0):
+        e, _, sf = m.encoder(audio_signal=torch.from_numpy(c).to(device), length=length)
+        m.decoder(encoder_output=e, encoder_output_scaling_factor=sf)
+    qm.evaluate(m)
+    log('calibrated; packing')
+    inputs = m.export_pack_inputs()
+    blob, meta = pack.pack_model(*inputs)
+    f = m.preprocessor.featurizer
+    return blob, meta, f.fb[0].detach().cpu().contiguous(), f.window.detach().cpu().contiguous(), inputs[2], inputs[3]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the integer engine has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)         # "nccl" is RCCL on ROCm
+
+    from qasr import engine, synth, topology
+    engine.load_library()
+    cfg = topology.MODELS[MODEL]()
+
+    # rank 0 calibrates + packs; the packed int weights travel to the other ranks over RCCL/xGMI
+    from qasr import dist as qdist
+    blob = meta = None
+    fb, window = torch.zeros(64, 257), torch.zeros(320)
+    if rank == 0:
+        blob, meta, fb, window, amin, amax = build_model(dev)
+    if world > 1:
+        blob = qdist.broadcast_bytes(blob, 0, dev)
+        fb, window = qdist.broadcast_tensors([fb, window], 0, dev)
+    fb, window = fb.to(dev), window.to(dev)
+    eng = engine.Engine(blob, local)
+    log(f'engine ready ({len(blob) / 1e6:.1f} MB blob); warm-up')
+
+    audio = torch.from_numpy(synth.make_audio(BATCH, SAMPLES, seed=100 + rank)).to(dev)
+    alen = torch.full((BATCH,), SAMPLES, dtype=torch.int32, device=dev)
+    T_out = eng.out_frames(engine.load_library().qasr_frontend_frames(SAMPLES, 16))
+    gathered = [torch.empty(BATCH, T_out, dtype=torch.int32, device=dev) for _ in range(world)] if rank == 0 else None
+
+    def step():
+        feats, flen = engine.frontend_mel(audio, alen, fb, window, 0.97, 16)
+        _, tokens, _ = eng.forward(feats, flen, want_logp=False)
+        if world > 1:
+            qdist.gather_tokens(tokens, 0, gathered)
+        return tokens
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tokens = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax[0])
+    audio_s = world * BATCH * SAMPLES / 16000.0 * args.steps
+    log(f'timed {args.steps} steps: {1e3 * dt / args.steps:.3f} ms/step')
+    result = {
+        'metric': 'RTFx (audio-sec/wall-sec) QuartzNet15x5 int8 bs32', 'value': audio_s / dt, 'unit': 'audio-s/wall-s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 's8 x s8 -> i32 (MFMA), f64 requant',
+        'data': 'synthetic',
+        'config': {'workload': 'QuartzNet15x5Base-En w8a8 percentile=99.996, bs=32/GPU, 5 s synthetic 16 kHz audio '
+                               '(500 mel frames): HIP mel front-end + integer encoder + CTC decoder + greedy argmax',
+                   'global_batch': BATCH * world, 'seq_len': FRAMES, 'weights': 'random-init (qasr.synth, seed 0)',
+                   'parallelism': f'utterance-sharded x{world}' + (', RCCL blob broadcast + token gather' if world > 1 else ''),
+                   'wer': 'not measurable here: no LibriSpeech / checkpoint in the image'},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel class (k_pw), HIP events per op on the launch stream -------------
+        # every op is replayed 20x back to back between one HIP event pair on the launch stream
+        # (qasr_engine_time_ops); buffers hold the real activations of the last timed step
+        ms = eng.time_ops(reps=20).astype(np.float64)
+        kinds = np.array(meta['kinds'])
+        mfma_ops, dw_ops, dw_bytes = algorithmic_work(cfg, BATCH, T_out)
+        t_pw = float(ms[kinds == 2].sum()) * 1e-3
+        t_dw = float(ms[kinds == 1].sum()) * 1e-3
+        n_pw = int((kinds == 2).sum())
+        achieved = mfma_ops / t_pw
+        result['roofline'] = {
+            'kernel': 'k_pw (int8 MFMA pointwise/residual/decoder GEMM + fused requant epilogue)',
+            'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': PEAK_INT8_OPS / 1e12, 'unit': 'TFLOP/s',
+            'frac': achieved / PEAK_INT8_OPS, 'traffic': None,
+            'launches_per_step': n_pw, 'avg_launch_us': 1e6 * t_pw / n_pw, 'ops_per_launch': mfma_ops / n_pw,
+            'other': {'k_dw_hbm_frac': (dw_bytes / t_dw) / PEAK_HBM, 'k_dw_ms_per_step': 1e3 * t_dw,
+                      'k_pw_ms_per_step': 1e3 * t_pw, 'all_ops_ms_per_step': float(ms.sum())},
+        }
+
+        # ---- CPU baseline: the reference's fake-quant op sequence on this host's cores (N=1 only) --------------
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.fakequant_torch import FakeQuantNet
+            cores = host_cores()
+            torch.set_num_threads(cores)
+            log(f'roofline pass done; CPU baseline on {cores} host threads')
+            sd = synth.make_state_dict(cfg, 0)
+            net = FakeQuantNet(topology.conv_plan(cfg), cfg, sd, amin, amax, 8, 8)
+            feats, _ = engine.frontend_mel(audio, alen, fb, window, 0.97, 16)
+            x = feats[:, :, :FRAMES].cpu().numpy()
+            lens = [FRAMES] * BATCH
+            net.forward(x[:4], lens[:4])                         # warm-up on a small slice
+            log('cpu baseline warm-up done')
+            t1 = time.perf_counter()
+            n_fwd = 2
+            for _ in range(n_fwd):
+                out = net.forward(x, lens)
+                log('cpu baseline forward done')
+            tc = (time.perf_counter() - t1) / n_fwd
+            agree = float((out['tokens'].numpy() == tokens.cpu().numpy()[:, :out['tokens'].shape[1]]).mean())
+            result['cpu_baseline'] = {
+                'value': BATCH * FRAMES * 0.01 / tc, 'unit': 'audio-s/wall-s', 'cores': torch.get_num_threads(),
+                'kind': 'port',
+                'sample': f'{n_fwd} forwards of encoder+decoder on the same 32x500-frame feature batch '
+                          f'({tc:.2f} s each; front-end excluded); token agreement with the GPU run {agree:.4f}'}
+        print(json.dumps(result))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

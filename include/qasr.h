@@ -125,7 +125,8 @@ typedef struct qasr_engine qasr_engine;
 /* Build an engine from a packed model.  Replaces model construction + `qm.evaluate(model)` state:
  * EncDecCTCModel.__init__ / encoder.bn_folding / calibrated QuantAct ranges
  * (nemo/collections/asr/models/ctc_models.py:91-147, examples/asr/quantization/inference.py:105-136).
- * `debug` != 0 keeps every intermediate tensor and int32 accumulator alive for qasr_engine_read_*. */
+ * `debug` bit 0 keeps every intermediate tensor and int32 accumulator alive for qasr_engine_read_*;
+ * bit 1 only records one HIP event per op on the launch stream (qasr_engine_last_op_ms), no other change. */
 int qasr_engine_create(const void* blob, size_t blob_bytes, int device, int debug, qasr_engine** out);
 void qasr_engine_destroy(qasr_engine* e);
 
@@ -148,6 +149,9 @@ int qasr_engine_read_acc(qasr_engine* e, int op, int pane, int32_t* host_out, si
 int qasr_engine_read_tensor(qasr_engine* e, int tensor, void* host_out, size_t n_bytes, int* T_out, int* Tp_out);
 /* average device time (ms) per op kind over the last forward, measured with HIP events (debug engines) */
 int qasr_engine_last_op_ms(qasr_engine* e, float* ms_per_op, int n_ops);
+/* Roofline hook: after a forward, replay each op `reps` times back to back between one pair of HIP events on
+ * `stream` and return the average duration per launch in ms (synchronises). */
+int qasr_engine_time_ops(qasr_engine* e, void* stream, int reps, float* ms_per_launch, int n_ops);
 
 /* ---- stand-alone operators (same kernels the engine launches; device pointers) -------------- */
 

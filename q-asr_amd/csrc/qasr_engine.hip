@@ -41,7 +41,8 @@ struct TensorRT {
 
 struct qasr_engine {
   int device = 0;
-  bool debug = false;
+  bool debug = false;                  // keep every tensor + dump int32 accumulators (parity hooks)
+  bool timing = false;                 // per-op HIP events (qasr_engine_last_op_ms)
   std::vector<uint8_t> blob;           // host copy
   uint8_t* dblob = nullptr;            // device copy
   qasr_blob_header h{};
@@ -55,6 +56,7 @@ struct qasr_engine {
   std::vector<void*> slots;            // owned device buffers
   std::vector<size_t> slot_bytes;
   int32_t* lens_all = nullptr;
+  int32_t* time_tokens = nullptr;      // scratch token buffer for qasr_engine_time_ops
   std::vector<std::vector<int32_t*>> acc_dbg;   // [op][1 + pane]
   std::vector<hipEvent_t> ev;          // debug timing: n_ops + 1 events
   bool timed = false;
@@ -77,6 +79,8 @@ static void free_plan(qasr_engine* e) {
   e->slot_bytes.clear();
   if (e->lens_all) (void)hipFree(e->lens_all);
   e->lens_all = nullptr;
+  if (e->time_tokens) (void)hipFree(e->time_tokens);
+  e->time_tokens = nullptr;
   for (auto& v : e->acc_dbg)
     for (auto p : v)
       if (p) (void)hipFree(p);
@@ -137,6 +141,7 @@ static int build_plan(qasr_engine* e, int B, int T0) {
     }
   }
   HIPCHK(hipMalloc((void**)&e->lens_all, sizeof(int32_t) * h.n_domains * B));
+  HIPCHK(hipMalloc((void**)&e->time_tokens, sizeof(int32_t) * (size_t)B * (T0 + 64)));
   if (e->debug) {
     e->acc_dbg.resize(h.n_ops);
     for (uint32_t oi = 0; oi < h.n_ops; ++oi) {
@@ -151,10 +156,10 @@ static int build_plan(qasr_engine* e, int B, int T0) {
         e->acc_dbg[oi].push_back(p);
       }
     }
-    if (e->ev.empty()) {
-      e->ev.resize(h.n_ops + 1);
-      for (auto& v : e->ev) HIPCHK(hipEventCreate(&v));
-    }
+  }
+  if (e->timing && e->ev.empty()) {
+    e->ev.resize(h.n_ops + 1);
+    for (auto& v : e->ev) HIPCHK(hipEventCreate(&v));
   }
   e->B = B;
   e->T0 = T0;
@@ -234,7 +239,8 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
   HIPCHK(hipSetDevice(device));
   qasr_engine* e = new qasr_engine();
   e->device = device;
-  e->debug = debug != 0;
+  e->debug = (debug & 1) != 0;
+  e->timing = (debug & 3) != 0;
   e->blob.assign((const uint8_t*)blob, (const uint8_t*)blob + n);
   e->h = h;
   e->tdesc = (const qasr_tensor_desc*)(e->blob.data() + h.tensors_off);
@@ -275,6 +281,108 @@ int qasr_engine_out_frames(const qasr_engine* e, int T) {
   return dT[e->tdesc[last.in].domain];
 }
 
+static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, int32_t* tokens, int32_t* lens_out) {
+  const qasr_op_desc& op = e->ops[oi];
+  const int B = e->B;
+  const TensorRT& tin = e->tens[op.in];
+  switch (op.kind) {
+    case QASR_OP_QUANT_IN: {
+      const TensorRT& to = e->tens[op.outs[0].tensor];
+      QuantInP p{};
+      p.x = (const float*)tin.ptr;
+      p.out = (int8_t*)to.ptr;
+      p.lens = e->lens_all + (size_t)to.d.domain * B;
+      p.inv_scale = op.in_inv_scale;
+      p.lo = op.qlo;
+      p.hi = op.qhi;
+      p.C = (int)op.cin;
+      p.T = tin.T;
+      p.Tp = to.Tp;
+      p.B = B;
+      launch_quant_in(s, p);
+      break;
+    }
+    case QASR_OP_DW: {
+      DwP p{};
+      p.x = (const int8_t*)tin.ptr;
+      p.w = dev_at<int8_t>(e, op.w_off);
+      p.bias = dev_at<int32_t>(e, op.bias_off);
+      p.C = (int)op.cin;
+      p.K = (int)op.kernel;
+      p.kpad = rup(p.K, 4);
+      p.stride = (int)op.stride;
+      p.dilation = (int)op.dilation;
+      p.padding = (int)op.padding;
+      p.T_in = tin.T;
+      p.Tp_in = tin.Tp;
+      p.x_unsigned = tin.d.dtype == QASR_DT_U8;
+      fill_epi(e, oi, op, p.e);
+      launch_dw(s, p);
+      break;
+    }
+    case QASR_OP_PW: {
+      PwP p{};
+      p.x = (const int8_t*)tin.ptr;
+      p.w = dev_at<int8_t>(e, op.w_off);
+      p.bias = dev_at<int32_t>(e, op.bias_off);
+      p.cin = (int)op.cin;
+      p.cin_pad = rup(p.cin, 64);
+      p.x_unsigned = tin.d.dtype == QASR_DT_U8;
+      p.n_panes = (int)op.n_panes;
+      fill_panes(e, oi, op, p.panes);
+      fill_epi(e, oi, op, p.e);
+      launch_pw(s, p);
+      break;
+    }
+    case QASR_OP_DENSE: {
+      DenseP p{};
+      p.x = (const int8_t*)tin.ptr;
+      p.w = dev_at<int8_t>(e, op.w_off);
+      p.bias = dev_at<int32_t>(e, op.bias_off);
+      p.cin = (int)op.cin;
+      p.cin_pad = rup(p.cin, 64);
+      p.K = (int)op.kernel;
+      p.stride = (int)op.stride;
+      p.dilation = (int)op.dilation;
+      p.padding = (int)op.padding;
+      p.T_in = tin.T;
+      p.Tp_in = tin.Tp;
+      p.x_unsigned = tin.d.dtype == QASR_DT_U8;
+      p.n_panes = (int)op.n_panes;
+      fill_panes(e, oi, op, p.panes);
+      fill_epi(e, oi, op, p.e);
+      launch_dense(s, p);
+      break;
+    }
+    case QASR_OP_REQUANT: {
+      const TensorRT& to = e->tens[op.outs[0].tensor];
+      RequantP p{};
+      p.in = tin.ptr;
+      p.in_is_i32 = tin.d.dtype == QASR_DT_I32;
+      fill_out(e, op.outs[0], p.out);
+      p.sb = dev_at<float>(e, op.sb_off);
+      p.lens = e->lens_all + (size_t)to.d.domain * B;
+      p.flags = op.flags & QASR_F_MASK_OUT;   // the stored value is already ReLU'd / round-tripped z
+      p.C = (int)op.cin;
+      p.T = to.T;
+      p.Tp = to.Tp;
+      p.B = B;
+      launch_requant(s, p);
+      break;
+    }
+    case QASR_OP_LOGSOFTMAX: {
+      launch_logsoftmax(s, (const float*)tin.ptr, logp, tokens, B * tin.T, (int)op.cin);
+      if (lens_out)
+        HIPCHK(hipMemcpyAsync(lens_out, e->lens_all + (size_t)tin.d.domain * B, sizeof(int32_t) * B,
+                              hipMemcpyDeviceToDevice, s));
+      break;
+    }
+    default:
+      return fail(QASR_ERR_UNSUPPORTED, "op kind %u", op.kind);
+  }
+  return QASR_OK;
+}
+
 int qasr_engine_forward(qasr_engine* e, void* stream, const float* feats, const int32_t* lens, int B, int T,
                         float* logp, int32_t* tokens, int32_t* lens_out) {
   if (!e || !feats || !lens || B <= 0 || T <= 0) return fail(QASR_ERR_ARG, "bad forward arguments");
@@ -288,110 +396,40 @@ int qasr_engine_forward(qasr_engine* e, void* stream, const float* feats, const 
   const qasr_domain_desc* ddoms = (const qasr_domain_desc*)(e->dblob + h.domains_off);
   launch_lens(s, lens, e->lens_all, ddoms, (int)h.n_domains, B);
   for (uint32_t oi = 0; oi < h.n_ops; ++oi) {
-    const qasr_op_desc& op = e->ops[oi];
-    if (e->debug) HIPCHK(hipEventRecord(e->ev[oi], s));
-    const TensorRT& tin = e->tens[op.in];
-    switch (op.kind) {
-      case QASR_OP_QUANT_IN: {
-        const TensorRT& to = e->tens[op.outs[0].tensor];
-        QuantInP p{};
-        p.x = (const float*)tin.ptr;
-        p.out = (int8_t*)to.ptr;
-        p.lens = e->lens_all + (size_t)to.d.domain * B;
-        p.inv_scale = op.in_inv_scale;
-        p.lo = op.qlo;
-        p.hi = op.qhi;
-        p.C = (int)op.cin;
-        p.T = tin.T;
-        p.Tp = to.Tp;
-        p.B = B;
-        launch_quant_in(s, p);
-        break;
-      }
-      case QASR_OP_DW: {
-        DwP p{};
-        p.x = (const int8_t*)tin.ptr;
-        p.w = dev_at<int8_t>(e, op.w_off);
-        p.bias = dev_at<int32_t>(e, op.bias_off);
-        p.C = (int)op.cin;
-        p.K = (int)op.kernel;
-        p.kpad = rup(p.K, 4);
-        p.stride = (int)op.stride;
-        p.dilation = (int)op.dilation;
-        p.padding = (int)op.padding;
-        p.T_in = tin.T;
-        p.Tp_in = tin.Tp;
-        p.x_unsigned = tin.d.dtype == QASR_DT_U8;
-        fill_epi(e, oi, op, p.e);
-        launch_dw(s, p);
-        break;
-      }
-      case QASR_OP_PW: {
-        PwP p{};
-        p.x = (const int8_t*)tin.ptr;
-        p.w = dev_at<int8_t>(e, op.w_off);
-        p.bias = dev_at<int32_t>(e, op.bias_off);
-        p.cin = (int)op.cin;
-        p.cin_pad = rup(p.cin, 64);
-        p.x_unsigned = tin.d.dtype == QASR_DT_U8;
-        p.n_panes = (int)op.n_panes;
-        fill_panes(e, oi, op, p.panes);
-        fill_epi(e, oi, op, p.e);
-        launch_pw(s, p);
-        break;
-      }
-      case QASR_OP_DENSE: {
-        DenseP p{};
-        p.x = (const int8_t*)tin.ptr;
-        p.w = dev_at<int8_t>(e, op.w_off);
-        p.bias = dev_at<int32_t>(e, op.bias_off);
-        p.cin = (int)op.cin;
-        p.cin_pad = rup(p.cin, 64);
-        p.K = (int)op.kernel;
-        p.stride = (int)op.stride;
-        p.dilation = (int)op.dilation;
-        p.padding = (int)op.padding;
-        p.T_in = tin.T;
-        p.Tp_in = tin.Tp;
-        p.x_unsigned = tin.d.dtype == QASR_DT_U8;
-        p.n_panes = (int)op.n_panes;
-        fill_panes(e, oi, op, p.panes);
-        fill_epi(e, oi, op, p.e);
-        launch_dense(s, p);
-        break;
-      }
-      case QASR_OP_REQUANT: {
-        const TensorRT& to = e->tens[op.outs[0].tensor];
-        RequantP p{};
-        p.in = tin.ptr;
-        p.in_is_i32 = tin.d.dtype == QASR_DT_I32;
-        fill_out(e, op.outs[0], p.out);
-        p.sb = dev_at<float>(e, op.sb_off);
-        p.lens = e->lens_all + (size_t)to.d.domain * B;
-        p.flags = op.flags & QASR_F_MASK_OUT;   // the stored value is already ReLU'd / round-tripped z
-        p.C = (int)op.cin;
-        p.T = to.T;
-        p.Tp = to.Tp;
-        p.B = B;
-        launch_requant(s, p);
-        break;
-      }
-      case QASR_OP_LOGSOFTMAX: {
-        launch_logsoftmax(s, (const float*)tin.ptr, logp, tokens, B * tin.T, (int)op.cin);
-        if (lens_out)
-          HIPCHK(hipMemcpyAsync(lens_out, e->lens_all + (size_t)tin.d.domain * B, sizeof(int32_t) * B,
-                                hipMemcpyDeviceToDevice, s));
-        break;
-      }
-      default:
-        return fail(QASR_ERR_UNSUPPORTED, "op kind %u", op.kind);
-    }
+    if (e->timing) HIPCHK(hipEventRecord(e->ev[oi], s));
+    int rc = launch_op(e, s, oi, logp, tokens, lens_out);
+    if (rc) return rc;
   }
-  if (e->debug) {
+  if (e->timing) {
     HIPCHK(hipEventRecord(e->ev[h.n_ops], s));
     e->timed = true;
   }
   HIPCHK(hipGetLastError());
+  return QASR_OK;
+}
+
+// Replays every op `reps` times back to back between ONE pair of HIP events on `stream` and returns the
+// average duration per launch (ms).  The buffers hold the activations of the last forward, so operands are
+// real data; each op reads its inputs and rewrites its own outputs, which makes the replay idempotent.
+int qasr_engine_time_ops(qasr_engine* e, void* stream, int reps, float* ms_per_launch, int n_ops) {
+  if (!e || !e->B || reps <= 0 || n_ops != (int)e->h.n_ops || !ms_per_launch) return fail(QASR_ERR_ARG, "time_ops: run a forward first");
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a));
+  HIPCHK(hipEventCreate(&b));
+  for (uint32_t oi = 0; oi < e->h.n_ops; ++oi) {
+    int rc = launch_op(e, s, oi, nullptr, e->time_tokens, nullptr);      // warm
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(a, s));
+    for (int r = 0; r < reps; ++r) launch_op(e, s, oi, nullptr, e->time_tokens, nullptr);
+    HIPCHK(hipEventRecord(b, s));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    ms_per_launch[oi] = ms / reps;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
   return QASR_OK;
 }
 
@@ -423,7 +461,7 @@ int qasr_engine_read_tensor(qasr_engine* e, int tensor, void* host_out, size_t n
 }
 
 int qasr_engine_last_op_ms(qasr_engine* e, float* ms, int n_ops) {
-  if (!e || !e->debug || !e->timed || n_ops != (int)e->h.n_ops) return fail(QASR_ERR_ARG, "last_op_ms: no timed forward");
+  if (!e || !e->timing || !e->timed || n_ops != (int)e->h.n_ops) return fail(QASR_ERR_ARG, "last_op_ms: no timed forward");
   HIPCHK(hipEventSynchronize(e->ev[n_ops]));
   for (int i = 0; i < n_ops; ++i) HIPCHK(hipEventElapsedTime(&ms[i], e->ev[i], e->ev[i + 1]));
   return QASR_OK;

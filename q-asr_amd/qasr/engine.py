@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, 'libqasr_hip.so')
 
 SYMBOLS = ['qasr_engine_create', 'qasr_engine_destroy', 'qasr_engine_forward', 'qasr_engine_out_frames',
            'qasr_engine_num_ops', 'qasr_engine_read_acc', 'qasr_engine_read_tensor', 'qasr_engine_last_op_ms',
+           'qasr_engine_time_ops',
            'qasr_frontend_mel', 'qasr_frontend_frames', 'qasr_frontend_workspace_bytes', 'qasr_pw_conv_acc',
            'qasr_dw_conv_acc', 'qasr_requant', 'qasr_last_error', 'qasr_version']
 
@@ -40,6 +41,7 @@ def load_library():
     lib.qasr_engine_read_acc.argtypes = [vp, i32, i32, vp, sz]
     lib.qasr_engine_read_tensor.argtypes = [vp, i32, vp, sz, C.POINTER(i32), C.POINTER(i32)]
     lib.qasr_engine_last_op_ms.argtypes = [vp, vp, i32]
+    lib.qasr_engine_time_ops.argtypes = [vp, vp, i32, vp, i32]
     lib.qasr_frontend_mel.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, C.c_float, i32, vp, vp, vp, sz]
     lib.qasr_frontend_frames.argtypes = [i32, i32]
     lib.qasr_frontend_workspace_bytes.argtypes = [i32, i32, i32]
@@ -70,7 +72,7 @@ def _ptr(t):
 class Engine:
     """One packed model on one GPU (qasr_engine_*)."""
 
-    def __init__(self, blob: bytes, device=0, debug=False):
+    def __init__(self, blob: bytes, device=0, debug=False, timing=False):
         lib = load_library()
         if not torch.cuda.is_available():
             raise QasrError('no GPU: the integer engine needs an MI355X (there is no CPU fallback)')
@@ -79,7 +81,8 @@ class Engine:
         self._blob = blob
         self._h = C.c_void_p()
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
-        _check(lib.qasr_engine_create(C.cast(buf, C.c_void_p), len(blob), device, int(debug), C.byref(self._h)),
+        _check(lib.qasr_engine_create(C.cast(buf, C.c_void_p), len(blob), device, int(bool(debug)) | (2 if timing else 0),
+                                      C.byref(self._h)),
                'qasr_engine_create')
         self.debug = debug
         self.n_ops = lib.qasr_engine_num_ops(self._h)
@@ -132,6 +135,13 @@ class Engine:
         _check(self.lib.qasr_engine_read_tensor(self._h, tensor, out.ctypes.data_as(C.c_void_p), out.nbytes,
                                                 C.byref(T), C.byref(Tp)), 'qasr_engine_read_tensor')
         return out[:, :, :T.value]
+
+    def time_ops(self, reps=20, stream=None):
+        """Average duration per launch (ms) of every op, each replayed `reps` times between one HIP event pair."""
+        ms = np.zeros(self.n_ops, dtype=np.float32)
+        _check(self.lib.qasr_engine_time_ops(self._h, _stream_ptr(stream), reps, ms.ctypes.data_as(C.c_void_p),
+                                             self.n_ops), 'qasr_engine_time_ops')
+        return ms
 
     def last_op_ms(self):
         ms = np.zeros(self.n_ops, dtype=np.float32)

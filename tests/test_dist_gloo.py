@@ -1,0 +1,81 @@
+"""N>1 path on CPU: two processes over gloo at 127.0.0.1 exercise the same helpers bench.py uses over RCCL —
+blob broadcast from the calibrating rank, contiguous utterance sharding, token gather to rank 0."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, golden_dir, q):
+    import torch.distributed as dist
+    from oracle import int_oracle as O
+    from qasr import dist as qdist, pack, synth, topology
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        d = np.load(os.path.join(golden_dir, 'net_miniq_w8a8.npz'))
+        meta = json.loads(str(d['meta']))
+        cfg = topology.mini_quartznet()
+        blob = None
+        if rank == 0:                                    # only rank 0 "calibrates" and packs
+            blob, _ = pack.pack_model(cfg, synth.make_state_dict(cfg, meta['seed']), d['act_min'], d['act_max'], 8, 8)
+        blob = qdist.broadcast_bytes(blob, 0, torch.device('cpu'))
+        ref_blob, _ = pack.pack_model(cfg, synth.make_state_dict(cfg, meta['seed']), d['act_min'], d['act_max'], 8, 8)
+        assert blob == ref_blob
+        # shard 5 utterances over 2 ranks, run the (CPU oracle) forward on the shard, gather ragged tokens
+        B = 5
+        x = synth.make_features(B, cfg.feat_in, 96, 21)
+        lens = [96, 80, 64, 50, 33]
+        lo, hi = qdist.shard_range(B, world, rank)
+        net = O.OracleNet(topology.conv_plan(cfg), cfg, synth.make_state_dict(cfg, meta['seed']), d['act_min'],
+                          d['act_max'], 8, 8)
+        tok = torch.from_numpy(net.forward(x[lo:hi], lens[lo:hi])['tokens'].astype(np.int32))
+        allt = qdist.gather_ragged_tokens(tok, 0)
+        eq = qdist.gather_tokens(torch.full((2, 3), rank, dtype=torch.int32), 0)
+        if rank == 0:
+            full = net.forward(x, lens)['tokens']
+            assert np.array_equal(allt.numpy(), full)
+            assert [int(t[0, 0]) for t in eq] == list(range(world))
+        else:
+            assert allt is None and eq is None
+        q.put((rank, 'ok'))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    from qasr.dist import shard_range
+    for n in (1, 5, 32, 255, 256):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gloo_broadcast_shard_gather(golden_dir):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, golden_dir, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert res == {0: 'ok', 1: 'ok'}, res
+    assert all(p.exitcode == 0 for p in procs)

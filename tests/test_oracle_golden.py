@@ -151,3 +151,25 @@ def test_ctc_greedy_decode():
     blank = len(vocab)
     toks = np.array([[3, 3, blank, 3, 1, 1, blank, blank, 20], [blank] * 9])
     assert O.ctc_greedy_decode(toks, vocab) == ['ccat', '']
+
+
+@pytest.mark.parametrize('name', NETS + ['net_quartznet_w8a8'])
+def test_cpu_baseline_port_matches_reference(golden_dir, name):
+    """oracle/fakequant_torch.py (the op sequence bench.py times as cpu_baseline) against the fixtures."""
+    from oracle.fakequant_torch import FakeQuantNet
+    d, meta = load(golden_dir, name)
+    cfg = _model_cfg(name)
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    net = FakeQuantNet(topology.conv_plan(cfg), cfg, sd, d['act_min'], d['act_max'], meta['wbit'], meta['abit'])
+    x = synth.make_features(meta['batch'], cfg.feat_in, meta['frames'], meta['seed'])
+    out = net.forward(x, meta['lengths'])
+    assert len(net.acc) == meta['nconv']
+    assert np.array_equal(out['tokens'].numpy(), d['tokens'])
+    assert np.array_equal(out['enc_len'].numpy(), d['enc_len'])
+    np.testing.assert_allclose(out['log_probs'].numpy(), d['log_probs'], rtol=1e-5, atol=1e-6)
+    for i, a in enumerate(net.acc):
+        yi = np.rint(a.numpy())
+        if f'acc_{i}' in d:
+            assert np.array_equal(yi.astype(np.int32), d[f'acc_{i}']), i
+        else:
+            assert np.array_equal(O.checksum(yi), d['conv_checksums'][i][:2]), i
