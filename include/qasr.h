@@ -88,7 +88,7 @@ enum {
 typedef struct qasr_pane {     /* one residual 1x1 conv feeding res_act (jasper.py:664-682) */
   int32_t in;                  /* tensor id (u8, already requantised for this conv's QuantAct) */
   uint32_t cin;
-  uint64_t w_off;              /* s8 [cout][cin_pad] */
+  uint64_t w_off;              /* s8, MFMA fragment order like the main 1x1 weights */
   uint64_t bias_off;           /* i32 [cout], includes the +128*sum(W) correction for u8 inputs */
   uint64_t m_off;              /* f64 [cout]: s_b[c] / S  as m*2^-e (batch_frexp) */
   uint64_t sb_off;             /* f32 [cout]: conv output scale (only read with QASR_F_EXACT_Z) */
@@ -108,7 +108,8 @@ typedef struct qasr_op_desc {
   int32_t in;                  /* main input tensor */
   uint32_t cin, cout, kernel, stride, dilation, padding;
   uint32_t n_panes;
-  uint64_t w_off;              /* s8 weights: DW [c][kpad], PW [cout][cin_pad], DENSE [cout][k][cin_pad] */
+  uint64_t w_off;              /* s8 weights: DW [c][kpad4]; PW cout_pad x cin_pad in MFMA fragment order (see
+                                  qasr_pw_conv_acc); DENSE [cout_pad][k][cin_pad] */
   uint64_t bias_off;           /* i32 [cout] (0 = none) */
   uint64_t m_off;              /* RESADD: f64 [cout] multiplier of the main accumulator towards S */
   uint64_t sb_off;             /* f32 [cout] conv output scale s_w[c]*s_x */
@@ -152,6 +153,8 @@ int qasr_engine_last_op_ms(qasr_engine* e, float* ms_per_op, int n_ops);
 /* Roofline hook: after a forward, replay each op `reps` times back to back between one pair of HIP events on
  * `stream` and return the average duration per launch in ms (synchronises). */
 int qasr_engine_time_ops(qasr_engine* e, void* stream, int reps, float* ms_per_launch, int n_ops);
+/* Re-enqueue a single op of the last forward's plan (diagnostics / profiling of one layer). */
+int qasr_engine_run_op(qasr_engine* e, void* stream, int op);
 
 /* ---- stand-alone operators (same kernels the engine launches; device pointers) -------------- */
 
@@ -167,8 +170,9 @@ int qasr_frontend_frames(int S, int pad_to);
 size_t qasr_frontend_workspace_bytes(int B, int S, int n_mels);
 
 /* QuantConv1d.int_conv accumulator only (quant_modules.py:301-305) for a 1x1 conv:
- * x i8 [B][cin][Tp] (x_unsigned: bytes are u8), w s8 [cout][cin_pad], bias i32 [cout] or NULL,
- * acc i32 [B][cout][Tp].  T valid columns. */
+ * x i8 [B][cin][Tp] (x_unsigned: bytes are u8, and bias must carry +128*sum(W)); bias i32 [cout_pad128] or NULL;
+ * w s8, cout_pad128 x cin_pad64 values in MFMA fragment order: byte ((tile*(cin_pad/32) + ks)*64 + lane)*16 + j holds
+ * W[32*tile + (lane & 31)][32*ks + 16*(lane >> 5) + j]; acc i32 [B][cout][Tp].  T valid columns. */
 int qasr_pw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, const int32_t* bias,
                      int B, int cin, int cin_pad, int cout, int T, int Tp, int32_t* acc);
 /* depthwise int_conv accumulator: w s8 [c][kpad]; acc i32 [B][c][Tp_out] */
@@ -179,6 +183,10 @@ int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t
  * with m[c] = mantissa*2^-e as f64; exact_z selects the float32 round trip through sb[c]. */
 int qasr_requant(void* stream, const int32_t* acc, const double* m, const float* sb, int exact_z, int relu,
                  int B, int c, int Tp, int lo, int hi, int8_t* out);
+
+/* Diagnostics: when set to a device buffer of 32 int64, work-group (1,0,0) of every k_sep launch writes s_memtime
+ * stamps at its phase boundaries (slot 31 = number of stamps); NULL (default) disables. */
+int qasr_debug_prof(void* dev_buf);
 
 const char* qasr_last_error(void);
 const char* qasr_version(void);

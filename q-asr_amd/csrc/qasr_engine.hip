@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -60,6 +61,10 @@ struct qasr_engine {
   std::vector<std::vector<int32_t*>> acc_dbg;   // [op][1 + pane]
   std::vector<hipEvent_t> ev;          // debug timing: n_ops + 1 events
   bool timed = false;
+  bool fuse = true;                    // fuse depthwise -> pointwise pairs into k_sep (QASR_NO_FUSE=1 disables)
+  bool legacy_pw = false;              // QASR_LEGACY_PW=1: stand-alone 1x1 convs through the v1 kernel k_pw
+  std::vector<int> fused_dw;           // per op: index of the DW op fused into this PW op, or -1
+  std::vector<char> skip;              // per op: launched as part of the following op
 };
 
 template <class T>
@@ -161,6 +166,19 @@ static int build_plan(qasr_engine* e, int B, int T0) {
     e->ev.resize(h.n_ops + 1);
     for (auto& v : e->ev) HIPCHK(hipEventCreate(&v));
   }
+  e->fused_dw.assign(h.n_ops, -1);
+  e->skip.assign(h.n_ops, 0);
+  if (e->fuse)
+    for (uint32_t oi = 0; oi + 1 < h.n_ops; ++oi) {
+      const qasr_op_desc& d = e->ops[oi];
+      const qasr_op_desc& q = e->ops[oi + 1];
+      if (d.kind != QASR_OP_DW || q.kind != QASR_OP_PW) continue;
+      if (d.stride != 1 || d.dilation != 1 || d.padding != d.kernel / 2 || !(d.kernel & 1) || !sep_supported((int)d.kernel)) continue;
+      if (d.outs[1].tensor >= 0 || d.outs[0].mode != 1 || q.in != d.outs[0].tensor) continue;
+      if (e->tdesc[d.outs[0].tensor].last_use != (int)oi + 1 || (d.flags & QASR_F_EXACT_Z)) continue;
+      e->fused_dw[oi + 1] = (int)oi;
+      e->skip[oi] = 1;
+    }
   e->B = B;
   e->T0 = T0;
   return QASR_OK;
@@ -224,6 +242,11 @@ extern "C" {
 const char* qasr_last_error(void) { return g_err.c_str(); }
 const char* qasr_version(void) { return "qasr-hip 0.1 (gfx950)"; }
 
+int qasr_debug_prof(void* dev_buf) {
+  qasr::g_prof = (long long*)dev_buf;
+  return QASR_OK;
+}
+
 int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_engine** out) {
   if (!blob || !out || n < sizeof(qasr_blob_header)) return fail(QASR_ERR_ARG, "null / short blob");
   qasr_blob_header h;
@@ -240,6 +263,8 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
   qasr_engine* e = new qasr_engine();
   e->device = device;
   e->debug = (debug & 1) != 0;
+  e->fuse = getenv("QASR_NO_FUSE") == nullptr;
+  e->legacy_pw = getenv("QASR_LEGACY_PW") != nullptr;
   e->timing = (debug & 3) != 0;
   e->blob.assign((const uint8_t*)blob, (const uint8_t*)blob + n);
   e->h = h;
@@ -284,6 +309,7 @@ int qasr_engine_out_frames(const qasr_engine* e, int T) {
 static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, int32_t* tokens, int32_t* lens_out) {
   const qasr_op_desc& op = e->ops[oi];
   const int B = e->B;
+  if (e->skip[oi]) return QASR_OK;        // runs inside the next op's k_sep launch
   const TensorRT& tin = e->tens[op.in];
   switch (op.kind) {
     case QASR_OP_QUANT_IN: {
@@ -321,6 +347,37 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
       break;
     }
     case QASR_OP_PW: {
+      if (!e->legacy_pw || e->fused_dw[oi] >= 0) {
+        SepP p{};
+        p.w = dev_at<int8_t>(e, op.w_off);
+        p.bias = dev_at<int32_t>(e, op.bias_off);
+        p.cin = (int)op.cin;
+        p.cin_pad = rup(p.cin, 64);
+        p.n_panes = (int)op.n_panes;
+        fill_panes(e, oi, op, p.panes);
+        fill_epi(e, oi, op, p.e);
+        const int di = e->fused_dw[oi];
+        if (di >= 0) {
+          const qasr_op_desc& d = e->ops[di];
+          const TensorRT& din = e->tens[d.in];
+          p.x = (const int8_t*)din.ptr;
+          p.wdw = dev_at<int8_t>(e, d.w_off);
+          p.bias_dw = dev_at<int32_t>(e, d.bias_off);
+          p.m_dw = dev_at<double>(e, d.outs[0].m_off);
+          p.dw_acc_dbg = (e->debug && !e->acc_dbg[di].empty()) ? e->acc_dbg[di][0] : nullptr;
+          p.dw_lo = d.outs[0].lo;
+          p.dw_hi = d.outs[0].hi;
+          p.K = (int)d.kernel;
+          p.x_unsigned = din.d.dtype == QASR_DT_U8;
+          p.pw_unsigned = 0;
+        } else {
+          p.x = (const int8_t*)tin.ptr;
+          p.K = 0;
+          p.pw_unsigned = tin.d.dtype == QASR_DT_U8;
+        }
+        launch_sep(s, p);
+        break;
+      }
       PwP p{};
       p.x = (const int8_t*)tin.ptr;
       p.w = dev_at<int8_t>(e, op.w_off);
@@ -433,6 +490,11 @@ int qasr_engine_time_ops(qasr_engine* e, void* stream, int reps, float* ms_per_l
   return QASR_OK;
 }
 
+int qasr_engine_run_op(qasr_engine* e, void* stream, int op) {
+  if (!e || !e->B || op < 0 || op >= (int)e->h.n_ops) return fail(QASR_ERR_ARG, "run_op: run a forward first");
+  return launch_op(e, (hipStream_t)stream, (uint32_t)op, nullptr, e->time_tokens, nullptr);
+}
+
 int qasr_engine_read_acc(qasr_engine* e, int op, int pane, int32_t* host_out, size_t n_elems) {
   if (!e || !e->debug || op < 0 || op >= (int)e->h.n_ops || e->acc_dbg.empty()) return fail(QASR_ERR_ARG, "read_acc: not a debug engine / bad op");
   const auto& v = e->acc_dbg[op];
@@ -486,13 +548,14 @@ int qasr_pw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t
   int rc = zero_buf(&z);
   if (rc) return rc;
   if ((size_t)rup(cout, 128) * 8 > kZeroBytes) return fail(QASR_ERR_ARG, "cout too large");
-  PwP p{};
+  SepP p{};                            // the production 1x1 kernel (k_sep<0>) with no consumers: accumulators only
   p.x = x;
   p.w = w;
   p.bias = bias ? bias : (const int32_t*)z;
   p.cin = cin;
   p.cin_pad = cin_pad;
-  p.x_unsigned = x_unsigned;
+  p.pw_unsigned = x_unsigned;
+  p.K = 0;
   p.e.sb = (const float*)z;
   p.e.acc_dbg = acc;
   p.e.T = T;
@@ -500,7 +563,7 @@ int qasr_pw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t
   p.e.cout = cout;
   p.e.B = B;
   p.e.lens = (const int32_t*)z;
-  launch_pw((hipStream_t)stream, p);
+  launch_sep((hipStream_t)stream, p);
   HIPCHK(hipGetLastError());
   return QASR_OK;
 }

@@ -68,6 +68,26 @@ struct DenseP {           // dense k>1 conv as implicit GEMM (+ residual panes)
   EpiP e;
 };
 
+struct SepP {             // fused separable layer: depthwise stencil -> QuantAct -> 1x1 GEMM (+ panes) -> epilogue
+  // depthwise stage (absent when K == 0: the 1x1 conv reads `x` directly)
+  const int8_t* x;        // [B][cin][Tp]   input of the depthwise conv (or of the 1x1 conv when K == 0)
+  const int8_t* wdw;      // [cin][kpad4]
+  const int32_t* bias_dw; // [cin_pad]  128*sum(w) for u8 inputs
+  const double* m_dw;     // [cin_pad]  requant of the dw accumulator towards the 1x1 conv's QuantAct
+  int32_t* dw_acc_dbg;    // optional i32 [B][cin][Tp]
+  int dw_lo, dw_hi;       // clamp of that QuantAct
+  int K, x_unsigned;      // taps (stride 1, dilation 1, 'same' padding)
+  // pointwise stage
+  const int8_t* w;        // [cout_pad][cin_pad]
+  const int32_t* bias;    // [cout_pad]
+  int cin, cin_pad, pw_unsigned, n_panes;
+  long long* prof;        // diagnostics: s_memtime stamps of work-group (0,0,0), wave 0 (qasr_debug_prof)
+  PaneP panes[QASR_MAX_PANES];
+  EpiP e;
+};
+
+extern long long* g_prof;
+
 struct QuantInP {
   const float* x;         // [B][C][T]
   int8_t* out;            // [B][C][Tp]
@@ -90,6 +110,8 @@ void launch_quant_in(hipStream_t s, const QuantInP& p);
 void launch_dw(hipStream_t s, const DwP& p);
 void launch_pw(hipStream_t s, const PwP& p);
 void launch_dense(hipStream_t s, const DenseP& p);
+bool sep_supported(int K);
+void launch_sep(hipStream_t s, const SepP& p);
 void launch_requant(hipStream_t s, const RequantP& p);
 void launch_logsoftmax(hipStream_t s, const float* logits, float* logp, int32_t* tokens, int rows, int ncls);
 void launch_lens(hipStream_t s, const int32_t* lens_in, int32_t* lens_all, const qasr_domain_desc* doms,

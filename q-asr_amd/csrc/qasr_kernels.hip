@@ -7,37 +7,9 @@
 //   k_quant_in / k_requant / k_logsoftmax / k_lens   small element-wise passes
 // Arithmetic contract: SURVEY.md Appendix A (reference: nemo/quantization/utils/quant_utils.py:163-216,
 // quant_modules.py:272-309).  Integer results are bit-exact; see DESIGN.md for the proofs used.
-#include "qasr_internal.h"
+#include "qasr_device.h"
 
 namespace qasr {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-
-#define MAGIC_RNE 6755399441055744.0 /* 1.5 * 2^52: fma(z, M, MAGIC) rounds z*M half-to-even into the low word */
-
-// clamp(rint(z * M), lo, hi): fixedpoint_mul.forward (quant_utils.py:196-198,213).  z*M is exact in fp64
-// for |z| < 2^22 (m < 2^31), otherwise it is the same single fp64 rounding the reference performs.
-// The clamp is applied in the double domain (MAGIC+lo, MAGIC+hi) so huge products cannot wrap the low word.
-__device__ __forceinline__ int requant_clamp(int z, double M, int lo, int hi) {
-  double t = __builtin_fma((double)z, M, MAGIC_RNE);
-  t = fmin(fmax(t, MAGIC_RNE + (double)lo), MAGIC_RNE + (double)hi);
-  return __double2loint(t);
-}
-// rint(z*M) as a double (RESADD sums two of these before clamping, quant_utils.py:211)
-__device__ __forceinline__ double requant_d(int z, double M) { return rint((double)z * M); }
-
-// z_int = round(x / pre_act_scaling_factor) of fixedpoint_mul (quant_utils.py:187) taken through the
-// float32 view y = fl32(fl32(acc) * s_b); equals acc whenever |acc| < 2^22 (then the caller skips this).
-__device__ __forceinline__ int z_roundtrip(int acc, float sb, bool relu) {
-  float y = __fmul_rn((float)acc, sb);
-  if (relu) y = fmaxf(y, 0.0f);
-  return (int)rintf(__fdiv_rn(y, sb));
-}
-
-__device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
-  return (unsigned)(a & 0xff) | ((unsigned)(b & 0xff) << 8) | ((unsigned)(c & 0xff) << 16) | ((unsigned)d << 24);
-}
 
 // ------------------------------------------------------------------------------------------------ lens
 __global__ void k_lens(const int32_t* lens_in, int32_t* lens_all, const qasr_domain_desc* doms, int n_domains, int B) {
@@ -79,18 +51,6 @@ __global__ void k_quant_in(QuantInP p) {
 void launch_quant_in(hipStream_t s, const QuantInP& p) {
   dim3 g((p.Tp / 4 + 63) / 64, p.C, p.B);
   hipLaunchKernelGGL(k_quant_in, g, dim3(64), 0, s, p);
-}
-
-// ------------------------------------------------------------------------------------------------ epilogue helpers
-// Integer result of one conv accumulator for the non-RESADD case: ReLU'd z.
-__device__ __forceinline__ int epi_z(int acc, const EpiP& e, float sb) {
-  bool relu = e.flags & QASR_F_RELU;
-  if (e.flags & QASR_F_EXACT_Z) return z_roundtrip(acc, sb, relu);
-  return relu ? max(acc, 0) : acc;
-}
-__device__ __forceinline__ int out_value(int z, const OutP& o, double Mc) {
-  if (o.mode == 2) return z;
-  return requant_clamp(z, o.mode == 1 ? Mc : o.m, o.lo, o.hi);
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise
@@ -242,10 +202,10 @@ __device__ __forceinline__ void pw_gemm(v16i& acc0, v16i& acc1, const int8_t* __
     const int kw = min(PW_KC, cin_pad - kc);            // multiple of 64
     // (1) weight fragments for this K chunk: W[co_row][kc + 32*ks + 16*h .. +15]
     v4i wf[PW_KC / 32];
-    const int8_t* wrow = w + (size_t)co_row * cin_pad + kc + 16 * h;
+    const v4i* wp = w_frag(w, cin_pad, co_row, kc >> 5);
 #pragma unroll
     for (int ks = 0; ks < PW_KC / 32; ++ks)
-      if (32 * ks < kw) wf[ks] = *(const v4i*)(wrow + 32 * ks);
+      if (32 * ks < kw) wf[ks] = wp[64 * ks];
     // (2) X chunk -> LDS, transposed: this wave stages input channels [kc + 64*wave, +64)
     if (64 * wave < kw) {
       const int ci0 = kc + 64 * wave + 4 * cq;

@@ -11,9 +11,9 @@ LIB_PATH = os.path.join(HERE, 'libqasr_hip.so')
 
 SYMBOLS = ['qasr_engine_create', 'qasr_engine_destroy', 'qasr_engine_forward', 'qasr_engine_out_frames',
            'qasr_engine_num_ops', 'qasr_engine_read_acc', 'qasr_engine_read_tensor', 'qasr_engine_last_op_ms',
-           'qasr_engine_time_ops',
+           'qasr_engine_time_ops', 'qasr_engine_run_op',
            'qasr_frontend_mel', 'qasr_frontend_frames', 'qasr_frontend_workspace_bytes', 'qasr_pw_conv_acc',
-           'qasr_dw_conv_acc', 'qasr_requant', 'qasr_last_error', 'qasr_version']
+           'qasr_dw_conv_acc', 'qasr_requant', 'qasr_debug_prof', 'qasr_last_error', 'qasr_version']
 
 _lib = None
 
@@ -42,6 +42,7 @@ def load_library():
     lib.qasr_engine_read_tensor.argtypes = [vp, i32, vp, sz, C.POINTER(i32), C.POINTER(i32)]
     lib.qasr_engine_last_op_ms.argtypes = [vp, vp, i32]
     lib.qasr_engine_time_ops.argtypes = [vp, vp, i32, vp, i32]
+    lib.qasr_engine_run_op.argtypes = [vp, vp, i32]
     lib.qasr_frontend_mel.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, C.c_float, i32, vp, vp, vp, sz]
     lib.qasr_frontend_frames.argtypes = [i32, i32]
     lib.qasr_frontend_workspace_bytes.argtypes = [i32, i32, i32]
@@ -49,6 +50,7 @@ def load_library():
     lib.qasr_pw_conv_acc.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.qasr_dw_conv_acc.argtypes = [vp, vp, i32, vp] + [i32] * 11 + [vp]
     lib.qasr_requant.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.qasr_debug_prof.argtypes = [vp]
     lib.qasr_last_error.restype = C.c_char_p
     lib.qasr_version.restype = C.c_char_p
     _lib = lib
@@ -143,6 +145,9 @@ class Engine:
                                              self.n_ops), 'qasr_engine_time_ops')
         return ms
 
+    def run_op(self, op, stream=None):
+        _check(self.lib.qasr_engine_run_op(self._h, _stream_ptr(stream), int(op)), 'qasr_engine_run_op')
+
     def last_op_ms(self):
         ms = np.zeros(self.n_ops, dtype=np.float32)
         _check(self.lib.qasr_engine_last_op_ms(self._h, ms.ctypes.data_as(C.c_void_p), self.n_ops), 'last_op_ms')
@@ -163,8 +168,10 @@ def pw_conv_acc(x: torch.Tensor, w: torch.Tensor, bias=None, x_unsigned=False):
     dev = x.device
     xp = torch.zeros(B, cin, Tp, dtype=torch.int8, device=dev)
     xp[:, :, :T] = x.view(torch.int8) if x.dtype == torch.uint8 else x
-    wp = torch.zeros(coutp, cinp, dtype=torch.int8, device=dev)
-    wp[:cout, :cin] = w.to(dev)
+    from .pack import fragment_order
+    wp = torch.zeros(coutp, cinp, dtype=torch.int8)
+    wp[:cout, :cin] = w.cpu()
+    wp = torch.from_numpy(fragment_order(wp.numpy())).to(dev)
     bp = torch.zeros(coutp, dtype=torch.int32, device=dev)
     if bias is not None:
         bp[:cout] = bias.to(dev)

@@ -31,6 +31,16 @@ COUT_ALIGN, CIN_ALIGN = 128, 64
 Z_EXACT_LIMIT = (1 << 22) - 1       # below this z == acc is a theorem
 
 
+def fragment_order(w: np.ndarray) -> np.ndarray:
+    """1x1 conv weights [cout_pad(128k)][cin_pad(64k)] -> MFMA B-fragment order (include/qasr.h):
+    byte ((tile*NKS + ks)*64 + lane)*16 + j  =  W[32*tile + (lane & 31)][32*ks + 16*(lane >> 5) + j],
+    so one wave instruction (64 lanes x 16 B) reads one contiguous 1 KiB block."""
+    cp, cinp = w.shape
+    assert cp % 32 == 0 and cinp % 32 == 0
+    v = w.reshape(cp // 32, 32, cinp // 32, 2, 16)          # [tile, r, ks, h, j]
+    return np.ascontiguousarray(v.transpose(0, 2, 3, 1, 4)).reshape(-1)   # [tile, ks, h, r, j]
+
+
 def _t(a):
     return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a))
 
@@ -290,6 +300,8 @@ class Packer:
         cinp = _rup(cin, CIN_ALIGN)
         w = torch.zeros(cp, k, cinp, dtype=torch.int8)
         w[:cout, :, :cin] = wi.permute(0, 2, 1).to(torch.int8)
+        if kind == OP_PW:
+            return self._put(fragment_order(w[:, 0, :].numpy()))
         return self._put(w.numpy())
 
     def _vec(self, t, rows, dtype, fill=0):
