@@ -101,6 +101,8 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--streams', type=int, default=int(os.environ.get('QASR_BENCH_STREAMS', 4)),
+                    help='independent steps in flight per GPU (each on its own HIP stream + engine arena)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -132,29 +134,36 @@ def main():
         blob = qdist.broadcast_bytes(blob, 0, dev)
         fb, window = qdist.broadcast_tensors([fb, window], 0, dev)
     fb, window = fb.to(dev), window.to(dev)
-    eng = engine.Engine(blob, local)
-    log(f'engine ready ({len(blob) / 1e6:.1f} MB blob); warm-up')
+    # throughput mode: consecutive steps are independent batches, so S of them are kept in flight, each on its own
+    # HIP stream with its own engine arena (kernels of different steps overlap each other's launch gaps and tails)
+    S = max(1, args.streams)
+    engs = [engine.Engine(blob, local) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    eng = engs[0]
+    log(f'{S} engine(s) ready ({len(blob) / 1e6:.1f} MB blob); warm-up')
 
     audio = torch.from_numpy(synth.make_audio(BATCH, SAMPLES, seed=100 + rank)).to(dev)
     alen = torch.full((BATCH,), SAMPLES, dtype=torch.int32, device=dev)
     T_out = eng.out_frames(engine.load_library().qasr_frontend_frames(SAMPLES, 16))
     gathered = [torch.empty(BATCH, T_out, dtype=torch.int32, device=dev) for _ in range(world)] if rank == 0 else None
 
-    def step():
-        feats, flen = engine.frontend_mel(audio, alen, fb, window, 0.97, 16)
-        _, tokens, _ = eng.forward(feats, flen, want_logp=False)
-        if world > 1:
-            qdist.gather_tokens(tokens, 0, gathered)
+    def step(i):
+        k = i % S
+        with torch.cuda.stream(streams[k]):
+            feats, flen = engine.frontend_mel(audio, alen, fb, window, 0.97, 16)
+            _, tokens, _ = engs[k].forward(feats, flen, want_logp=False)
+            if world > 1:
+                qdist.gather_tokens(tokens, 0, gathered)
         return tokens
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(max(args.warmup, S)):
+        step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tokens = step()
+    for i in range(args.steps):
+        tokens = step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -173,7 +182,7 @@ def main():
         'config': {'workload': 'QuartzNet15x5Base-En w8a8 percentile=99.996, bs=32/GPU, 5 s synthetic 16 kHz audio '
                                '(500 mel frames): HIP mel front-end + integer encoder + CTC decoder + greedy argmax',
                    'global_batch': BATCH * world, 'seq_len': FRAMES, 'weights': 'random-init (qasr.synth, seed 0)',
-                   'parallelism': f'utterance-sharded x{world}' + (', RCCL blob broadcast + token gather' if world > 1 else ''),
+                   'steps_in_flight': S, 'parallelism': f'utterance-sharded x{world}' + (', RCCL blob broadcast + token gather' if world > 1 else ''),
                    'wer': 'not measurable here: no LibriSpeech / checkpoint in the image'},
     }
 
@@ -184,17 +193,22 @@ def main():
         ms = eng.time_ops(reps=20).astype(np.float64)
         kinds = np.array(meta['kinds'])
         mfma_ops, dw_ops, dw_bytes = algorithmic_work(cfg, BATCH, T_out)
-        t_pw = float(ms[kinds == 2].sum()) * 1e-3
-        t_dw = float(ms[kinds == 1].sum()) * 1e-3
-        n_pw = int((kinds == 2).sum())
-        achieved = mfma_ops / t_pw
+        # k_sep launches = every PW op (a fused depthwise stage reports 0 ms on its own op slot)
+        t_sep = float(ms[kinds == 2].sum()) * 1e-3
+        t_dw = float(ms[kinds == 1].sum()) * 1e-3                # depthwise layers that still run stand-alone
+        n_sep = int((kinds == 2).sum())
+        n_fused = int(((kinds == 1) & (ms < 1e-3)).sum())
+        achieved = mfma_ops / t_sep                              # MFMA-class ops only: the fused dw taps run on VALU
         result['roofline'] = {
-            'kernel': 'k_pw (int8 MFMA pointwise/residual/decoder GEMM + fused requant epilogue)',
+            'kernel': 'k_sep (fused depthwise stencil -> int8 MFMA 1x1 GEMM -> requant / res_act epilogue)',
             'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': PEAK_INT8_OPS / 1e12, 'unit': 'TFLOP/s',
             'frac': achieved / PEAK_INT8_OPS, 'traffic': None,
-            'launches_per_step': n_pw, 'avg_launch_us': 1e6 * t_pw / n_pw, 'ops_per_launch': mfma_ops / n_pw,
-            'other': {'k_dw_hbm_frac': (dw_bytes / t_dw) / PEAK_HBM, 'k_dw_ms_per_step': 1e3 * t_dw,
-                      'k_pw_ms_per_step': 1e3 * t_pw, 'all_ops_ms_per_step': float(ms.sum())},
+            'launches_per_step': n_sep, 'avg_launch_us': 1e6 * t_sep / n_sep, 'ops_per_launch': mfma_ops / n_sep,
+            'other': {'fused_depthwise_layers': n_fused, 'depthwise_gop_inside_k_sep': dw_ops / 1e9,
+                      'standalone_dw_ms_per_step': 1e3 * t_dw, 'k_sep_ms_per_step': 1e3 * t_sep,
+                      'all_ops_ms_per_step_serial': float(ms.sum()),
+                      'timing': 'each op replayed 20x between one HIP event pair on the launch stream, no other work '
+                                'in flight'},
         }
 
         # ---- CPU baseline: the reference's fake-quant op sequence on this host's cores (N=1 only) --------------
@@ -223,7 +237,8 @@ def main():
                 'sample': f'{n_fwd} forwards of encoder+decoder on the same 32x500-frame feature batch '
                           f'({tc:.2f} s each; front-end excluded); token agreement with the GPU run {agree:.4f}'}
         print(json.dumps(result))
-    eng.close()
+    for e_ in engs:
+        e_.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -162,7 +162,8 @@ int qasr_engine_run_op(qasr_engine* e, void* stream, int op);
  * (nemo/collections/asr/parts/features.py:334-397): pre-emphasis, STFT(512, hop 160, hann 320),
  * power, mel filterbank, log, per-feature normalisation, mask, pad to a multiple of `pad_to`.
  * audio f32 [B][S]; audio_lens i32 [B] (samples); fb f32 [n_mels][257]; window f32 [320];
- * feats f32 [B][n_mels][T_pad]; feat_lens i32 [B].  T_pad = qasr_frontend_frames(S, pad_to). */
+ * feats f32 [B][n_mels][T_pad]; feat_lens i32 [B].  T_pad = qasr_frontend_frames(S, pad_to).
+ * workspace: device scratch of qasr_frontend_workspace_bytes(B, S, n_mels) bytes (non-zero run of every mel filter). */
 int qasr_frontend_mel(void* stream, const float* audio, const int32_t* audio_lens, int B, int S,
                       const float* fb, const float* window, int n_mels, float preemph, int pad_to,
                       float* feats, int32_t* feat_lens, void* workspace, size_t workspace_bytes);

@@ -173,7 +173,8 @@ static int build_plan(qasr_engine* e, int B, int T0) {
       const qasr_op_desc& d = e->ops[oi];
       const qasr_op_desc& q = e->ops[oi + 1];
       if (d.kind != QASR_OP_DW || q.kind != QASR_OP_PW) continue;
-      if (d.stride != 1 || d.dilation != 1 || d.padding != d.kernel / 2 || !(d.kernel & 1) || !sep_supported((int)d.kernel)) continue;
+      const uint32_t same_pad = d.dilation > 1 ? (d.dilation * d.kernel) / 2 - 1 : d.kernel / 2;
+      if (d.stride != 1 || d.padding != same_pad || !(d.kernel & 1) || !sep_supported((int)d.kernel, (int)d.dilation)) continue;
       if (d.outs[1].tensor >= 0 || d.outs[0].mode != 1 || q.in != d.outs[0].tensor) continue;
       if (e->tdesc[d.outs[0].tensor].last_use != (int)oi + 1 || (d.flags & QASR_F_EXACT_Z)) continue;
       e->fused_dw[oi + 1] = (int)oi;
@@ -368,11 +369,13 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
           p.dw_lo = d.outs[0].lo;
           p.dw_hi = d.outs[0].hi;
           p.K = (int)d.kernel;
+          p.dilation = (int)d.dilation;
           p.x_unsigned = din.d.dtype == QASR_DT_U8;
           p.pw_unsigned = 0;
         } else {
           p.x = (const int8_t*)tin.ptr;
           p.K = 0;
+          p.dilation = 1;
           p.pw_unsigned = tin.d.dtype == QASR_DT_U8;
         }
         launch_sep(s, p);
@@ -556,6 +559,7 @@ int qasr_pw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t
   p.cin_pad = cin_pad;
   p.pw_unsigned = x_unsigned;
   p.K = 0;
+  p.dilation = 1;
   p.e.sb = (const float*)z;
   p.e.acc_dbg = acc;
   p.e.T = T;

@@ -27,73 +27,104 @@ __device__ __forceinline__ float sample(const float* x, int S, int i, float pree
   return v;
 }
 
+// The mel matrix is sparse (each triangular filter covers a short run of FFT bins): k_melrange finds the non-zero
+// run of every filter once per call, k_mel then multiplies only inside it.  Skipped terms are fma(0, P, acc) = acc,
+// so the float result is identical to the dense product.
+__global__ void k_melrange(const float* __restrict__ fb, int n_mels, int* __restrict__ ranges) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_mels) return;
+  int lo = NBIN, hi = 0;
+  for (int k = 0; k < NBIN; ++k)
+    if (fb[(size_t)m * NBIN + k] != 0.f) {
+      lo = min(lo, k);
+      hi = k + 1;
+    }
+  ranges[2 * m] = min(lo, hi);
+  ranges[2 * m + 1] = hi;
+}
+
+// every wave owns its FFT buffers, so stages are separated by a wave-level fence instead of a work-group barrier:
+// DS operations of one wave execute in issue order, the fence only stops the compiler from reordering them
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#define MEL_FPW 2                          /* frames per wave per work-group (4 waves) */
 __global__ void __launch_bounds__(256) k_mel(const float* __restrict__ audio, int B, int S, const float* __restrict__ fb,
-                                             const float* __restrict__ window, int n_mels, float preemph, int n_frames,
-                                             int T_pad, float* __restrict__ out) {
+                                             const float* __restrict__ window, const int* __restrict__ ranges, int n_mels,
+                                             float preemph, int n_frames, int T_pad, float* __restrict__ out) {
   __shared__ float re[4][NFFT], im[4][NFFT];
   __shared__ float twc[NFFT / 2], tws[NFFT / 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // twiddles exp(-2*pi*i*k/512), k < 256
   {
     float s, c;
-    sincospif(-2.0f * (float)tid / (float)NFFT, &s, &c);
+    sincospif(-2.0f * (float)tid / (float)NFFT, &s, &c);   // twiddles exp(-2*pi*i*k/512), k < 256
     twc[tid] = c;
     tws[tid] = s;
   }
-  const int fidx = blockIdx.x * 4 + wave;            // frame index over B * n_frames
-  const bool ok = fidx < B * n_frames;
-  const int b = ok ? fidx / n_frames : 0, t = ok ? fidx - b * n_frames : 0;
-  const float* x = audio + (size_t)b * S;
-  // framing: sample j of frame t is ypad[160 t + j], ypad index 0 <-> signal index -256
-#pragma unroll
-  for (int i = 0; i < NFFT / 64; ++i) {
-    const int j = lane + 64 * i;
-    float v = 0.f;
-    if (j >= WOFF && j < WOFF + WIN) v = __fmul_rn(sample(x, S, HOP * t + j - NFFT / 2, preemph), window[j - WOFF]);
-    const int r = bitrev9(j);
-    re[wave][r] = v;
-    im[wave][r] = 0.f;
-  }
   __syncthreads();
-  // in-place radix-2 DIT, 9 stages, 4 butterflies per lane per stage
+  float* wre = re[wave];
+  float* wim = im[wave];
+  for (int it = 0; it < MEL_FPW; ++it) {
+    const int fidx = (blockIdx.x * MEL_FPW + it) * 4 + wave;   // frame index over B * n_frames
+    const bool ok = fidx < B * n_frames;
+    const int b = ok ? fidx / n_frames : 0, t = ok ? fidx - b * n_frames : 0;
+    const float* x = audio + (size_t)b * S;
+    wave_sync_lds();                       // previous frame's spectrum consumed
+    // framing: sample j of frame t is ypad[160 t + j], ypad index 0 <-> signal index -256
+#pragma unroll
+    for (int i = 0; i < NFFT / 64; ++i) {
+      const int j = lane + 64 * i;
+      float v = 0.f;
+      if (j >= WOFF && j < WOFF + WIN) v = __fmul_rn(sample(x, S, HOP * t + j - NFFT / 2, preemph), window[j - WOFF]);
+      const int r = bitrev9(j);
+      wre[r] = v;
+      wim[r] = 0.f;
+    }
+    wave_sync_lds();
+    // in-place radix-2 DIT, 9 stages, 4 butterflies per lane per stage
 #pragma unroll 1
-  for (int s = 1; s <= 9; ++s) {
-    const int half = 1 << (s - 1), m = half << 1, tstep = NFFT / m;
+    for (int s = 1; s <= 9; ++s) {
+      const int half = 1 << (s - 1), m = half << 1, tstep = NFFT / m;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = lane + 64 * q;
-      const int pos = i & (half - 1), grp = i >> (s - 1);
-      const int a = grp * m + pos, bb = a + half;
-      const float wr = twc[pos * tstep], wi = tws[pos * tstep];
-      const float xr = re[wave][bb], xi = im[wave][bb];
-      const float tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
-      const float ar = re[wave][a], ai = im[wave][a];
-      re[wave][a] = ar + tr;
-      im[wave][a] = ai + ti;
-      re[wave][bb] = ar - tr;
-      im[wave][bb] = ai - ti;
+      for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
+        const int pos = i & (half - 1), grp = i >> (s - 1);
+        const int a = grp * m + pos, bb = a + half;
+        const float wr = twc[pos * tstep], wi = tws[pos * tstep];
+        const float xr = wre[bb], xi = wim[bb];
+        const float tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
+        const float ar = wre[a], ai = wim[a];
+        wre[a] = ar + tr;
+        wim[a] = ai + ti;
+        wre[bb] = ar - tr;
+        wim[bb] = ai - ti;
+      }
+      wave_sync_lds();
     }
-    __syncthreads();
-  }
-  // power spectrum: the reference takes sqrt(re^2+im^2) and then pow(2) (features.py:356-360)
+    // power spectrum: the reference takes sqrt(re^2+im^2) and then pow(2) (features.py:356-360)
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int k = lane + 64 * i;
-    if (k < NBIN) {
-      const float r = re[wave][k], q = im[wave][k];
-      const float mag = sqrtf(r * r + q * q);
-      re[wave][k] = mag * mag;
+    for (int i = 0; i < 5; ++i) {
+      const int k = lane + 64 * i;
+      if (k < NBIN) {
+        const float r = wre[k], q = wim[k];
+        const float mag = sqrtf(r * r + q * q);
+        wre[k] = mag * mag;
+      }
     }
-  }
-  __syncthreads();
-  // mel projection + log (features.py:363-368); lane = mel bin
-  for (int m0 = 0; m0 < n_mels; m0 += 64) {
-    const int m = m0 + lane;
-    if (m < n_mels && ok) {
-      const float* f = fb + (size_t)m * NBIN;
-      float acc = 0.f;
-      for (int k = 0; k < NBIN; ++k) acc = fmaf(f[k], re[wave][k], acc);
-      out[((size_t)b * n_mels + m) * T_pad + t] = logf(acc + 5.9604644775390625e-08f);   // 2^-24
+    wave_sync_lds();
+    // mel projection + log (features.py:363-368); lane = mel bin
+    for (int m0 = 0; m0 < n_mels; m0 += 64) {
+      const int m = m0 + lane;
+      if (m < n_mels && ok) {
+        const float* f = fb + (size_t)m * NBIN;
+        const int lo = ranges[2 * m], hi = ranges[2 * m + 1];
+        float acc = 0.f;
+        for (int k = lo; k < hi; ++k) acc = fmaf(f[k], wre[k], acc);
+        out[((size_t)b * n_mels + m) * T_pad + t] = logf(acc + 5.9604644775390625e-08f);   // 2^-24
+      }
     }
   }
 }
@@ -133,19 +164,23 @@ int qasr_frontend_frames(int S, int pad_to) {
   return n;
 }
 
-size_t qasr_frontend_workspace_bytes(int, int, int) { return 0; }   // the feature buffer doubles as scratch
+size_t qasr_frontend_workspace_bytes(int, int, int n_mels) { return (size_t)n_mels * 2 * sizeof(int); }
 
 int qasr_frontend_mel(void* stream, const float* audio, const int32_t* audio_lens, int B, int S, const float* fb,
                       const float* window, int n_mels, float preemph, int pad_to, float* feats, int32_t* feat_lens,
-                      void*, size_t) {
-  if (!audio || !audio_lens || !fb || !window || !feats || !feat_lens || B <= 0 || S <= NFFT / 2 || n_mels <= 0)
+                      void* workspace, size_t workspace_bytes) {
+  if (!audio || !audio_lens || !fb || !window || !feats || !feat_lens || B <= 0 || S <= NFFT / 2 || n_mels <= 0 ||
+      !workspace || workspace_bytes < (size_t)n_mels * 2 * sizeof(int))
     return QASR_ERR_ARG;
   const int n_frames = 1 + S / HOP;
   const int T_pad = qasr_frontend_frames(S, pad_to);
   hipStream_t s = (hipStream_t)stream;
   const int frames = B * n_frames;
-  hipLaunchKernelGGL(qasr::k_mel, dim3((frames + 3) / 4), dim3(256), 0, s, audio, B, S, fb, window, n_mels, preemph,
-                     n_frames, T_pad, feats);
+  int* ranges = (int*)workspace;
+  hipLaunchKernelGGL(qasr::k_melrange, dim3((n_mels + 63) / 64), dim3(64), 0, s, fb, n_mels, ranges);
+  const int per_wg = 4 * MEL_FPW;
+  hipLaunchKernelGGL(qasr::k_mel, dim3((frames + per_wg - 1) / per_wg), dim3(256), 0, s, audio, B, S, fb, window, ranges,
+                     n_mels, preemph, n_frames, T_pad, feats);
   hipLaunchKernelGGL(qasr::k_norm, dim3(B * n_mels), dim3(64), 0, s, feats, audio_lens, n_mels, n_frames, T_pad,
                      feat_lens);
   return hipGetLastError() == hipSuccess ? QASR_OK : QASR_ERR_HIP;

@@ -76,7 +76,8 @@ struct SepP {             // fused separable layer: depthwise stencil -> QuantAc
   const double* m_dw;     // [cin_pad]  requant of the dw accumulator towards the 1x1 conv's QuantAct
   int32_t* dw_acc_dbg;    // optional i32 [B][cin][Tp]
   int dw_lo, dw_hi;       // clamp of that QuantAct
-  int K, x_unsigned;      // taps (stride 1, dilation 1, 'same' padding)
+  int K, x_unsigned;      // taps (stride 1, 'same' padding)
+  int dilation, pad2_;    // 1, or 2 (window staged de-interleaved by parity)
   // pointwise stage
   const int8_t* w;        // [cout_pad][cin_pad]
   const int32_t* bias;    // [cout_pad]
@@ -110,7 +111,7 @@ void launch_quant_in(hipStream_t s, const QuantInP& p);
 void launch_dw(hipStream_t s, const DwP& p);
 void launch_pw(hipStream_t s, const PwP& p);
 void launch_dense(hipStream_t s, const DenseP& p);
-bool sep_supported(int K);
+bool sep_supported(int K, int dilation);
 void launch_sep(hipStream_t s, const SepP& p);
 void launch_requant(hipStream_t s, const RequantP& p);
 void launch_logsoftmax(hipStream_t s, const float* logits, float* logp, int32_t* tokens, int rows, int ncls);

@@ -24,15 +24,20 @@ long long* g_prof = nullptr;
 #define SEP_NT 512
 #define SEP_OP 48            // output staging row pitch (32 frames + 16)
 
-template <int K>
+// DIL == 2 (block 16, k = 87): out[t] = sum_k w[k] x[t - 86 + 2k] only touches frames of t's parity, so the window is
+// staged de-interleaved (one LDS row per channel and parity) and each parity stream sees an ordinary stride-1 conv with
+// PAD = K/2 stream samples; a task is then (channel, parity) = 16 outputs t0 + parity + 2*o.
+template <int K, int DIL>
 struct SepGeo {
-  static constexpr int PAD = K / 2;
-  static constexpr int HALO = (PAD + 15) / 16 * 16;        // staged halo, 16-B granular
+  static constexpr int PAD = K / 2;                         // in stream samples
+  static constexpr int HALO = (PAD + 15) / 16 * 16;        // staged halo, 16-B granular (stream samples)
   static constexpr int D = HALO - PAD;                      // byte offset of the first tap inside the staged window
   static constexpr int KP4 = (K + 3) / 4;
-  static constexpr int WLEN = SEP_TT + 2 * HALO;            // staged bytes per channel row
+  static constexpr int WLEN = SEP_TT / DIL + 2 * HALO;      // staged bytes per LDS row
   static constexpr int WP = WLEN + 16;                      // LDS row pitch of the window
   static constexpr int NX = KP4 + 5;                        // window dwords a lane reads for 16 outputs
+  static constexpr int CHUNK = 256 / DIL;                   // channels staged at a time (256 LDS rows)
+  static constexpr int NPG = DIL * WLEN / 16;               // 16-B global granules per channel
 };
 
 // ---- stage an input tile [cin][32] into LDS transposed as Xs[frame][channel] (4x4 byte transposes) ------------
@@ -124,9 +129,9 @@ __device__ __forceinline__ SepLaneP sep_lane_params(const SepP& p, int cor) {
 // DBG adds the int32 accumulator dumps of the parity hooks.
 enum { EP_GENERIC = 0, EP_PLAIN = 1, EP_RESADD1 = 2 };
 
-template <int K, int EP, bool DBG>
+template <int K, int DIL, int EP, bool DBG>
 __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
-  using G = SepGeo<(K > 0 ? K : 1)>;
+  using G = SepGeo<(K > 0 ? K : 1), DIL>;
   constexpr bool GEN = EP == EP_GENERIC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const EpiP& e = p.e;
@@ -170,22 +175,23 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
   if (K > 0) {
     // ------------------------------------------------------------------ depthwise stage
     const unsigned flip = p.x_unsigned ? 0x80808080u : 0u;
-    constexpr int NP = G::WLEN / 16;                         // 16-B pieces per staged row
-    constexpr int NPT = (256 * NP + SEP_NT - 1) / SEP_NT;    // pieces per thread per 256-channel chunk
+    constexpr int NP = G::NPG;                               // 16-B global granules per channel
+    constexpr int CH = G::CHUNK;                             // channels per staged chunk
+    constexpr int NPT = (CH * NP + SEP_NT - 1) / SEP_NT;     // granules per thread per chunk
     v4i pc[NPT];
     auto fetch = [&](int c0) {                               // global -> registers (coalesced 16-B granules)
-      const int nch = min(256, p.cin - c0);
+      const int nch = min(CH, p.cin - c0);
 #pragma unroll
       for (int i = 0; i < NPT; ++i) {
         const int pi = tid + SEP_NT * i;
         const int row = pi / NP, col = pi - row * NP;
-        const int t = t0 - G::HALO + 16 * col;               // granule entirely inside or outside [0, Tp)
+        const int t = t0 - DIL * G::HALO + 16 * col;         // granule entirely inside or outside [0, Tp)
         pc[i] = (v4i){0, 0, 0, 0};
         if (row < nch && t >= 0 && t < eTp) pc[i] = *(const v4i*)(p.x + ((size_t)b * p.cin + c0 + row) * eTp + t);
       }
     };
     auto commit = [&](int c0) {                              // registers -> LDS window
-      const int nch = min(256, p.cin - c0);
+      const int nch = min(CH, p.cin - c0);
 #pragma unroll
       for (int i = 0; i < NPT; ++i) {
         const int pi = tid + SEP_NT * i;
@@ -193,13 +199,20 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
         if (row < nch) {
           v4i v = pc[i];
           v[0] ^= flip; v[1] ^= flip; v[2] ^= flip; v[3] ^= flip;
-          *(v4i*)(Ws + row * G::WP + 16 * col) = v;
+          if (DIL == 1) {
+            *(v4i*)(Ws + row * G::WP + 16 * col) = v;
+          } else {                                           // de-interleave: even frames -> row 2c, odd -> row 2c+1
+            const unsigned e0 = __builtin_amdgcn_perm(v[1], v[0], 0x06040200u), e1 = __builtin_amdgcn_perm(v[3], v[2], 0x06040200u);
+            const unsigned o0 = __builtin_amdgcn_perm(v[1], v[0], 0x07050301u), o1 = __builtin_amdgcn_perm(v[3], v[2], 0x07050301u);
+            *(uint2*)(Ws + (2 * row) * G::WP + 8 * col) = make_uint2(e0, e1);
+            *(uint2*)(Ws + (2 * row + 1) * G::WP + 8 * col) = make_uint2(o0, o1);
+          }
         }
       }
     };
     fetch(0);
-    for (int c0 = 0; c0 < p.cin; c0 += 256) {
-      const int nch = min(256, p.cin - c0);
+    for (int c0 = 0; c0 < p.cin; c0 += CH) {
+      const int nch = min(CH, p.cin - c0);
       // taps / parameters of this thread's first task of the chunk: issued before the barrier they do not depend on
       const int task0 = tid;
       const bool has0 = task0 < nch * 2;
@@ -215,10 +228,10 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
       if (c0) __syncthreads();                               // previous chunk's window fully consumed
       commit(c0);
       __syncthreads();
-      if (c0 + 256 < p.cin) fetch(c0 + 256);                 // next chunk's window travels during this chunk's math
+      if (c0 + CH < p.cin) fetch(c0 + CH);                   // next chunk's window travels during this chunk's math
       STAMP();
       for (int task = tid; task < nch * 2; task += SEP_NT) {
-        const int row = task >> 1, hq = task & 1;            // 16 consecutive frames of one channel
+        const int row = task >> 1, hq = task & 1;            // DIL 1: 16 consecutive frames; DIL 2: one parity
         const int c = c0 + row;
         if (task != task0) {
           const int* wk = (const int*)(p.wdw + (size_t)c * (G::KP4 * 4));
@@ -227,7 +240,8 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
           bias = p.bias_dw[c];
           M = p.m_dw[c];
         }
-        const unsigned* wrow = (const unsigned*)(Ws + row * G::WP) + 4 * hq + (G::D >> 2);
+        const unsigned* wrow = (DIL == 1) ? (const unsigned*)(Ws + row * G::WP) + 4 * hq + (G::D >> 2)
+                                          : (const unsigned*)(Ws + (2 * row + hq) * G::WP) + (G::D >> 2);
         unsigned xw[G::NX];
 #pragma unroll
         for (int i = 0; i < G::NX; ++i) xw[i] = wrow[i];
@@ -248,16 +262,17 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
             acc[4 * j + s] = a;
           }
         }
-        const int tb = t0 + 16 * hq;
+        // output o of the task is local frame fl(o)
+        auto fl = [&](int o) { return DIL == 1 ? 16 * hq + o : hq + 2 * o; };
         if (DBG && p.dw_acc_dbg) {
 #pragma unroll
           for (int o = 0; o < 16; ++o)
-            if (tb + o < eT) p.dw_acc_dbg[((size_t)b * p.cin + c) * eTp + tb + o] = acc[o];
+            if (t0 + fl(o) < eT) p.dw_acc_dbg[((size_t)b * p.cin + c) * eTp + t0 + fl(o)] = acc[o];
         }
         int qv[16];
         requant_batch<16>(qv, acc, M, dw_lo, dw_hi);
 #pragma unroll
-        for (int o = 0; o < 16; ++o) Xs[(16 * hq + o) * XP + c] = (unsigned char)((tb + o < dlim) ? qv[o] : 0);
+        for (int o = 0; o < 16; ++o) Xs[fl(o) * XP + c] = (unsigned char)((t0 + fl(o) < dlim) ? qv[o] : 0);
       }
       STAMP();
     }
@@ -430,25 +445,28 @@ static size_t sep_smem_bytes(const SepP& p, int WP) {
   size_t xs = (size_t)SEP_TT * (p.cin_pad + 16);
   size_t xr = 0;
   for (int k = 0; k < p.n_panes; ++k) xr = std::max(xr, (size_t)SEP_TT * (p.panes[k].cin_pad + 16));
-  size_t ws = std::max((size_t)256 * WP, (size_t)256 * SEP_OP);
+  size_t ws = std::max((size_t)256 * WP, (size_t)256 * SEP_OP);   // 256 LDS rows in either dilation mode
   return xs + xr + ws;
 }
 
-bool sep_supported(int K) { return K == 0 || K == 11 || K == 13 || K == 33 || K == 39 || K == 51 || K == 63 || K == 75; }
+bool sep_supported(int K, int dilation) {
+  if (dilation == 2) return K == 87 || K == 15;
+  return dilation == 1 && (K == 0 || K == 11 || K == 13 || K == 33 || K == 39 || K == 51 || K == 63 || K == 75);
+}
 
-template <int K, int EP, bool DBG>
+template <int K, int DIL, int EP, bool DBG>
 static void launch_sep_v(hipStream_t s, const SepP& p) {
-  using G = SepGeo<(K > 0 ? K : 1)>;
+  using G = SepGeo<(K > 0 ? K : 1), DIL>;
   const size_t smem = sep_smem_bytes(p, K > 0 ? G::WP : SEP_OP);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_sep<K, EP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_sep<K, DIL, EP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   dim3 g(p.e.Tp / SEP_TT, 1, p.e.B);
   SepP q = p;
   q.prof = g_prof;
-  hipLaunchKernelGGL((k_sep<K, EP, DBG>), g, dim3(SEP_NT), smem, s, q);
+  hipLaunchKernelGGL((k_sep<K, DIL, EP, DBG>), g, dim3(SEP_NT), smem, s, q);
 }
 
 // which specialised epilogue covers this op
@@ -468,22 +486,27 @@ static int sep_epilogue_class(const SepP& p) {
   return EP_PLAIN;
 }
 
-template <int K>
+template <int K, int DIL = 1>
 static void launch_sep_k(hipStream_t s, const SepP& p) {
   const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
   const int ep = sep_epilogue_class(p);
   if (dbg) {
-    if (ep == EP_PLAIN) launch_sep_v<K, EP_PLAIN, true>(s, p);
-    else if (ep == EP_RESADD1) launch_sep_v<K, EP_RESADD1, true>(s, p);
-    else launch_sep_v<K, EP_GENERIC, true>(s, p);
+    if (ep == EP_PLAIN) launch_sep_v<K, DIL, EP_PLAIN, true>(s, p);
+    else if (ep == EP_RESADD1) launch_sep_v<K, DIL, EP_RESADD1, true>(s, p);
+    else launch_sep_v<K, DIL, EP_GENERIC, true>(s, p);
   } else {
-    if (ep == EP_PLAIN) launch_sep_v<K, EP_PLAIN, false>(s, p);
-    else if (ep == EP_RESADD1) launch_sep_v<K, EP_RESADD1, false>(s, p);
-    else launch_sep_v<K, EP_GENERIC, false>(s, p);
+    if (ep == EP_PLAIN) launch_sep_v<K, DIL, EP_PLAIN, false>(s, p);
+    else if (ep == EP_RESADD1) launch_sep_v<K, DIL, EP_RESADD1, false>(s, p);
+    else launch_sep_v<K, DIL, EP_GENERIC, false>(s, p);
   }
 }
 
 void launch_sep(hipStream_t s, const SepP& p) {
+  if (p.dilation == 2) {
+    if (p.K == 87) launch_sep_k<87, 2>(s, p);
+    else if (p.K == 15) launch_sep_k<15, 2>(s, p);
+    return;
+  }
   switch (p.K) {
     case 0: launch_sep_k<0>(s, p); break;
     case 11: launch_sep_k<11>(s, p); break;

@@ -232,6 +232,9 @@ def frontend_mel(audio: torch.Tensor, lens: torch.Tensor, fb: torch.Tensor, wind
     l32 = lens.to(device=dev, dtype=torch.int32).contiguous()
     fbd = fb.to(device=dev, dtype=torch.float32).contiguous()
     wd = window.to(device=dev, dtype=torch.float32).contiguous()
+    ws_bytes = lib.qasr_frontend_workspace_bytes(B, S, n_mels)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
     _check(lib.qasr_frontend_mel(_stream_ptr(), _ptr(a), _ptr(l32), B, S, _ptr(fbd), _ptr(wd), n_mels,
-                                 C.c_float(preemph), pad_to, _ptr(feats), _ptr(flens), None, 0), 'qasr_frontend_mel')
+                                 C.c_float(preemph), pad_to, _ptr(feats), _ptr(flens), _ptr(ws), ws.numel()),
+           'qasr_frontend_mel')
     return feats, flens
