@@ -172,7 +172,7 @@ size_t qasr_frontend_workspace_bytes(int B, int S, int n_mels);
 
 /* QuantConv1d.int_conv accumulator only (quant_modules.py:301-305) for a 1x1 conv:
  * x i8 [B][cin][Tp] (x_unsigned: bytes are u8, and bias must carry +128*sum(W)); bias i32 [cout_pad128] or NULL;
- * w s8, cout_pad128 x cin_pad64 values in MFMA fragment order: byte ((tile*(cin_pad/32) + ks)*64 + lane)*16 + j holds
+ * w s8, cout_pad128 x cin_pad128 values in MFMA fragment order: byte ((tile*(cin_pad/32) + ks)*64 + lane)*16 + j holds
  * W[32*tile + (lane & 31)][32*ks + 16*(lane >> 5) + j]; acc i32 [B][cout][Tp].  T valid columns. */
 int qasr_pw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, const int32_t* bias,
                      int B, int cin, int cin_pad, int cout, int T, int Tp, int32_t* acc);

@@ -25,7 +25,7 @@ __device__ __forceinline__ int requant_clamp(int z, double M, int lo, int hi) {
 // The wave votes once for a whole batch of values, so the fallback costs one uniform branch.
 #define REQ_TAU 1.3e-4f
 __device__ __forceinline__ float requant_f32(int z, float Mf, float lo1, float hi1) {
-  return fminf(fmaxf(__fmul_rn((float)z, Mf), lo1), hi1);
+  return __builtin_amdgcn_fmed3f(__fmul_rn((float)z, Mf), lo1, hi1);       // one v_med3_f32
 }
 __device__ __forceinline__ bool requant_ambiguous(float pc) { return 0.5f - fabsf(pc - rintf(pc)) <= REQ_TAU; }
 

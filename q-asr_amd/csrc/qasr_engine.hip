@@ -232,7 +232,7 @@ static void fill_panes(const qasr_engine* e, int oi, const qasr_op_desc& op, Pan
     d.sb = dev_at<float>(e, s.sb_off);
     d.acc_dbg = e->debug ? e->acc_dbg[oi][1 + k] : nullptr;
     d.cin = (int)s.cin;
-    d.cin_pad = rup((int)s.cin, 64);
+    d.cin_pad = rup((int)s.cin, 128);
     d.x_unsigned = t.d.dtype == QASR_DT_U8;
     d.pad_ = 0;
   }
@@ -353,7 +353,7 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
         p.w = dev_at<int8_t>(e, op.w_off);
         p.bias = dev_at<int32_t>(e, op.bias_off);
         p.cin = (int)op.cin;
-        p.cin_pad = rup(p.cin, 64);
+        p.cin_pad = rup(p.cin, 128);
         p.n_panes = (int)op.n_panes;
         fill_panes(e, oi, op, p.panes);
         fill_epi(e, oi, op, p.e);
@@ -386,7 +386,7 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
       p.w = dev_at<int8_t>(e, op.w_off);
       p.bias = dev_at<int32_t>(e, op.bias_off);
       p.cin = (int)op.cin;
-      p.cin_pad = rup(p.cin, 64);
+      p.cin_pad = rup(p.cin, 128);
       p.x_unsigned = tin.d.dtype == QASR_DT_U8;
       p.n_panes = (int)op.n_panes;
       fill_panes(e, oi, op, p.panes);
@@ -400,7 +400,7 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
       p.w = dev_at<int8_t>(e, op.w_off);
       p.bias = dev_at<int32_t>(e, op.bias_off);
       p.cin = (int)op.cin;
-      p.cin_pad = rup(p.cin, 64);
+      p.cin_pad = rup(p.cin, 128);
       p.K = (int)op.kernel;
       p.stride = (int)op.stride;
       p.dilation = (int)op.dilation;
@@ -546,7 +546,7 @@ static int zero_buf(void** p) {
 
 int qasr_pw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, const int32_t* bias, int B,
                      int cin, int cin_pad, int cout, int T, int Tp, int32_t* acc) {
-  if (!x || !w || !acc || cin_pad % 64 || Tp % 64 || T > Tp) return fail(QASR_ERR_ARG, "pw_conv_acc: bad arguments");
+  if (!x || !w || !acc || cin_pad % 128 || Tp % 64 || T > Tp) return fail(QASR_ERR_ARG, "pw_conv_acc: bad arguments");
   void* z;
   int rc = zero_buf(&z);
   if (rc) return rc;

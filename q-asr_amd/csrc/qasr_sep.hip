@@ -21,7 +21,10 @@ namespace qasr {
 long long* g_prof = nullptr;
 
 #define SEP_TT 32
-#define SEP_NT 512
+#ifndef SEP_NT
+#define SEP_NT 512          // threads per work-group (8 waves); 256 was measured slower at every concurrency level
+#endif
+#define SEP_PASS (SEP_NT / 2)  // output channels per GEMM pass (32 per wave)
 #define SEP_OP 48            // output staging row pitch (32 frames + 16)
 
 // DIL == 2 (block 16, k = 87): out[t] = sum_k w[k] x[t - 86 + 2k] only touches frames of t's parity, so the window is
@@ -66,21 +69,29 @@ __device__ __forceinline__ void sep_stage_transposed(unsigned char* Xs, int XP, 
 // Global-load latency under load is 2.5-4k cycles here while a 32x32x32 MFMA takes 32, so the whole slab is
 // requested at once (64 VGPRs): one exposed latency per GEMM instead of one per chunk.
 #define SEP_WK 16
+// cin_pad is a multiple of 128 (pack.py CIN_ALIGN): K steps come in unconditional groups of 4, so the compiler
+// emits 4 loads / 4 LDS reads / 4 MFMAs back to back instead of a branch + wait per step.
 __device__ __forceinline__ void sep_load_w(v4i (&wf)[SEP_WK], const int8_t* __restrict__ w, int cin_pad, int co_row, int kc) {
   const v4i* wp = w_frag(w, cin_pad, co_row, kc >> 5);        // consecutive K steps are 1 KiB apart
 #pragma unroll
-  for (int ks = 0; ks < SEP_WK; ++ks)
-    if (kc + 32 * ks < cin_pad) wf[ks] = wp[64 * ks];
+  for (int g = 0; g < SEP_WK / 4; ++g)
+    if (kc + 128 * g < cin_pad) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[4 * g + i] = wp[64 * (4 * g + i)];
+    }
 }
 __device__ __forceinline__ void sep_mfma_chunk(v16i& acc, const v4i (&wf)[SEP_WK], const unsigned char* Xs, int XP, int cin_pad,
                                                int kc) {
   const int lane = threadIdx.x & 63, h = lane >> 5, r31 = lane & 31;
   const unsigned char* arow = Xs + r31 * XP + kc + 16 * h;
 #pragma unroll
-  for (int ks = 0; ks < SEP_WK; ++ks)
-    if (kc + 32 * ks < cin_pad) {
-      const v4i a = *(const v4i*)(arow + 32 * ks);
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, wf[ks], acc, 0, 0, 0);
+  for (int g = 0; g < SEP_WK / 4; ++g)
+    if (kc + 128 * g < cin_pad) {
+      v4i a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *(const v4i*)(arow + 32 * (4 * g + i));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], wf[4 * g + i], acc, 0, 0, 0);
     }
 }
 // 32 frames x 32 channels x cin_pad GEMM for one wave; `wf` holds slab 0 already (requested by the caller ahead of
@@ -136,7 +147,10 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const EpiP& e = p.e;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int t0 = blockIdx.x * SEP_TT, b = blockIdx.z;
+  // XCD-aware mapping: work-groups are dealt round-robin over the 8 XCDs by linear id, so the utterance index is the
+  // fastest grid dimension - all time tiles of utterance b (whose depthwise windows overlap) and the layer that
+  // produced them run on XCD b % 8 and find their halos / inputs in that XCD's L2.
+  const int b = blockIdx.x, t0 = blockIdx.y * SEP_TT;
   const int XP = p.cin_pad + 16;
   unsigned char* Xs = smem;                                  // [32][XP]   A operand of the main GEMM
   unsigned char* Xr = Xs + SEP_TT * XP;                      // [32][XPr]  A operand of the residual GEMMs
@@ -158,7 +172,7 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
   const bool f_logits = GEN && (flags & QASR_F_LOGITS);
   const int n_panes = GEN ? p.n_panes : (EP == EP_RESADD1 ? 1 : 0);
   const int dw_lo = p.dw_lo, dw_hi = p.dw_hi;
-  const bool stamp = p.prof && blockIdx.x == 1 && blockIdx.z == 0 && tid == 0;
+  const bool stamp = p.prof && blockIdx.x == 0 && blockIdx.y == 1 && tid == 0;
   int nst = 0;
 #define STAMP() do { if (stamp && nst < 31) p.prof[nst++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   STAMP();
@@ -171,6 +185,7 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
   SepLaneP lp = sep_lane_params<EP>(p, in0 ? co_l : 0);
   v4i wf[SEP_WK];
   sep_load_w(wf, p.w, p.cin_pad, in0 ? co_l : 0, 0);        // consumed after the depthwise stage, which hides it
+  __builtin_amdgcn_sched_barrier(0);                         // keep the requests up here (the scheduler sinks them to first use)
 
   if (K > 0) {
     // ------------------------------------------------------------------ depthwise stage
@@ -292,7 +307,7 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
   STAMP();
 
   // ---------------------------------------------------------------------- pointwise GEMM passes of 256 channels
-  for (int cbase = 0; cbase < cout_pad; cbase += 256) {
+  for (int cbase = 0; cbase < cout_pad; cbase += SEP_PASS) {
     const int co = cbase + co_l;
     const bool co_in = co < cout_pad;                        // wave-uniform (cout_pad is a multiple of 128)
     const int cor = co_in ? co : 0;
@@ -303,8 +318,8 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
     for (int r = 0; r < 16; ++r) acc[r] = cur.bias;
     if (co_in) sep_gemm(acc, wf, Xs, XP, p.w, p.cin_pad, cor);
     // prefetch what the NEXT GEMM of this wave needs while the epilogue below runs
-    const bool more = cbase + 256 < cout_pad;
-    const int con = more ? ((cbase + 256 + co_l < cout_pad) ? cbase + 256 + co_l : 0) : 0;
+    const bool more = cbase + SEP_PASS < cout_pad;
+    const int con = more ? ((cbase + SEP_PASS + co_l < cout_pad) ? cbase + SEP_PASS + co_l : 0) : 0;
     SepLaneP nxt = cur;
     if (f_resadd && n_panes > 0) sep_load_w(wf, p.panes[0].w, p.panes[0].cin_pad, cor, 0);
     if (more) {
@@ -429,7 +444,7 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
       __syncthreads();
       STAMP();
       {
-        const int row = tid >> 1, half = tid & 1;            // 256 rows x 2 halves of 16 B
+        const int row = tid >> 1, half = tid & 1;            // SEP_PASS rows x 2 halves of 16 B
         const int cow = cbase + row;
         if (cow < ecout)
           *(v4i*)((int8_t*)optr + ((size_t)b * ecout + cow) * eTp + t0 + 16 * half) = *(const v4i*)(Ws + row * SEP_OP + 16 * half);
@@ -463,7 +478,7 @@ static void launch_sep_v(hipStream_t s, const SepP& p) {
     (void)hipFuncSetAttribute((const void*)k_sep<K, DIL, EP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dim3 g(p.e.Tp / SEP_TT, 1, p.e.B);
+  dim3 g(p.e.B, p.e.Tp / SEP_TT, 1);
   SepP q = p;
   q.prof = g_prof;
   hipLaunchKernelGGL((k_sep<K, DIL, EP, DBG>), g, dim3(SEP_NT), smem, s, q);

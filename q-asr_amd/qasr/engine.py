@@ -164,7 +164,7 @@ def pw_conv_acc(x: torch.Tensor, w: torch.Tensor, bias=None, x_unsigned=False):
     lib = load_library()
     B, cin, T = x.shape
     cout = w.shape[0]
-    Tp, cinp, coutp = _rup(T, 64), _rup(cin, 64), _rup(cout, 128)
+    Tp, cinp, coutp = _rup(T, 64), _rup(cin, 128), _rup(cout, 128)
     dev = x.device
     xp = torch.zeros(B, cin, Tp, dtype=torch.int8, device=dev)
     xp[:, :, :T] = x.view(torch.int8) if x.dtype == torch.uint8 else x

@@ -27,7 +27,7 @@ OP_QUANT_IN, OP_DW, OP_PW, OP_DENSE, OP_LOGSOFTMAX, OP_REQUANT = range(6)
 F_RELU, F_MASK_OUT, F_EXACT_Z, F_LOGITS, F_RESADD = 1, 2, 4, 8, 16
 DT_S8, DT_U8, DT_F32, DT_I32 = range(4)
 MAX_PANES, MAX_OUTS = 12, 3
-COUT_ALIGN, CIN_ALIGN = 128, 64
+COUT_ALIGN, CIN_ALIGN = 128, 128
 Z_EXACT_LIMIT = (1 << 22) - 1       # below this z == acc is a theorem
 
 
