@@ -24,6 +24,9 @@ for p in (os.path.join(ROOT, 'q-asr_amd'), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# steps in flight live on separate HIP streams; ROCm maps streams onto 4 hardware queues by default
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -101,6 +104,7 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--whole-utterance', action='store_true', help='use the k_utt kernels (one work-group per utterance)')
     ap.add_argument('--streams', type=int, default=int(os.environ.get('QASR_BENCH_STREAMS', 4)),
                     help='independent steps in flight per GPU (each on its own HIP stream + engine arena)')
     args = ap.parse_args()
@@ -137,7 +141,7 @@ def main():
     # throughput mode: consecutive steps are independent batches, so S of them are kept in flight, each on its own
     # HIP stream with its own engine arena (kernels of different steps overlap each other's launch gaps and tails)
     S = max(1, args.streams)
-    engs = [engine.Engine(blob, local) for _ in range(S)]
+    engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     eng = engs[0]
     log(f'{S} engine(s) ready ({len(blob) / 1e6:.1f} MB blob); warm-up')
@@ -152,8 +156,14 @@ def main():
         with torch.cuda.stream(streams[k]):
             feats, flen = engine.frontend_mel(audio, alen, fb, window, 0.97, 16)
             _, tokens, _ = engs[k].forward(feats, flen, want_logp=False)
-            if world > 1:
-                qdist.gather_tokens(tokens, 0, gathered)
+            done = torch.cuda.Event()
+            done.record(streams[k])
+        if world > 1:
+            # one communicator: the per-step gathers are issued in step order on the default stream, each behind its
+            # step's compute stream; compute of later steps keeps running on the other streams
+            torch.cuda.current_stream().wait_event(done)
+            tokens.record_stream(torch.cuda.current_stream())
+            qdist.gather_tokens(tokens, 0, gathered)
         return tokens
 
     for i in range(max(args.warmup, S)):
@@ -182,7 +192,7 @@ def main():
         'config': {'workload': 'QuartzNet15x5Base-En w8a8 percentile=99.996, bs=32/GPU, 5 s synthetic 16 kHz audio '
                                '(500 mel frames): HIP mel front-end + integer encoder + CTC decoder + greedy argmax',
                    'global_batch': BATCH * world, 'seq_len': FRAMES, 'weights': 'random-init (qasr.synth, seed 0)',
-                   'steps_in_flight': S, 'parallelism': f'utterance-sharded x{world}' + (', RCCL blob broadcast + token gather' if world > 1 else ''),
+                   'steps_in_flight': S, 'kernels': 'k_utt' if args.whole_utterance else 'k_sep', 'parallelism': f'utterance-sharded x{world}' + (', RCCL blob broadcast + token gather' if world > 1 else ''),
                    'wer': 'not measurable here: no LibriSpeech / checkpoint in the image'},
     }
 

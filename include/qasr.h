@@ -127,7 +127,9 @@ typedef struct qasr_engine qasr_engine;
  * EncDecCTCModel.__init__ / encoder.bn_folding / calibrated QuantAct ranges
  * (nemo/collections/asr/models/ctc_models.py:91-147, examples/asr/quantization/inference.py:105-136).
  * `debug` bit 0 keeps every intermediate tensor and int32 accumulator alive for qasr_engine_read_*;
- * bit 1 only records one HIP event per op on the launch stream (qasr_engine_last_op_ms), no other change. */
+ * bit 1 only records one HIP event per op on the launch stream (qasr_engine_last_op_ms), no other change;
+ * bit 2 selects the whole-utterance kernels (k_utt: one work-group per utterance and layer, T <= 256 frames) instead of
+ * the 32-frame tiles of k_sep - same results, meant for many steps in flight. */
 int qasr_engine_create(const void* blob, size_t blob_bytes, int device, int debug, qasr_engine** out);
 void qasr_engine_destroy(qasr_engine* e);
 

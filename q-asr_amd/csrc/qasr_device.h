@@ -49,6 +49,26 @@ __device__ __forceinline__ void requant_batch(int (&q)[N], const int (&z)[N], do
   }
 }
 
+// same with one multiplier per group of 4 consecutive values (4 channels x 4 values in the whole-utterance kernel)
+template <int N>
+__device__ __forceinline__ void requant_batch4(int (&q)[N], const int (&z)[N], const double (&M)[N / 4], int lo, int hi) {
+  const float lo1 = (float)(lo - 1), hi1 = (float)(hi + 1);
+  bool amb = false;
+  float pc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    pc[i] = requant_f32(z[i], (float)M[i / 4], lo1, hi1);
+    amb |= requant_ambiguous(pc[i]);
+  }
+  if (__builtin_expect(__any(amb), 0)) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = requant_clamp(z[i], M[i / 4], lo, hi);
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = min(max((int)rintf(pc[i]), lo), hi);
+  }
+}
+
 // rint(z*M) as a double (RESADD sums two of these before clamping, quant_utils.py:211)
 __device__ __forceinline__ double requant_d(int z, double M) { return rint((double)z * M); }
 

@@ -65,6 +65,9 @@ struct qasr_engine {
   bool legacy_pw = false;              // QASR_LEGACY_PW=1: stand-alone 1x1 convs through the v1 kernel k_pw
   std::vector<int> fused_dw;           // per op: index of the DW op fused into this PW op, or -1
   std::vector<char> skip;              // per op: launched as part of the following op
+  bool use_utt = true;                 // throughput mode: whole-utterance kernels (QASR_NO_UTT=1 disables)
+  std::vector<char> utt;               // per op: 0 = k_sep, 1 = k_utt plain, 2 = k_utt residual pair (rq32 + add32)
+  int32_t* r32 = nullptr;              // scratch [B][max cout][Tp] of the residual pair
 };
 
 template <class T>
@@ -86,6 +89,8 @@ static void free_plan(qasr_engine* e) {
   e->lens_all = nullptr;
   if (e->time_tokens) (void)hipFree(e->time_tokens);
   e->time_tokens = nullptr;
+  if (e->r32) (void)hipFree(e->r32);
+  e->r32 = nullptr;
   for (auto& v : e->acc_dbg)
     for (auto p : v)
       if (p) (void)hipFree(p);
@@ -180,6 +185,37 @@ static int build_plan(qasr_engine* e, int B, int T0) {
       e->fused_dw[oi + 1] = (int)oi;
       e->skip[oi] = 1;
     }
+  e->utt.assign(h.n_ops, 0);
+  size_t r32_elems = 0;
+  if (e->use_utt && e->fuse)
+    for (uint32_t oi = 0; oi < h.n_ops; ++oi) {
+      const qasr_op_desc& q = e->ops[oi];
+      if (q.kind != QASR_OP_PW || (q.flags & QASR_F_LOGITS)) continue;
+      const TensorRT& o0 = e->tens[q.outs[0].tensor];
+      const int Tp = rup(o0.T, 64);
+      const int di = e->fused_dw[oi];
+      int K = 0, dil = 1;
+      if (di >= 0) {
+        K = (int)e->ops[di].kernel;
+        dil = (int)e->ops[di].dilation;
+      }
+      if (!utt_supported(K, dil, Tp, rup((int)q.cin, 128), (int)q.cin) || q.cout > 1024) continue;
+      bool ok = true;
+      if (q.flags & QASR_F_RESADD) {
+        if (q.n_panes != 1 || !utt_supported(0, 1, Tp, rup((int)q.panes[0].cin, 128), (int)q.panes[0].cin)) continue;
+        for (int j = 0; j < QASR_MAX_OUTS; ++j)
+          if (q.outs[j].tensor >= 0 && q.outs[j].mode != 0 && q.outs[j].mode != 2) ok = false;
+        if (!ok) continue;
+        e->utt[oi] = 2;
+        r32_elems = std::max(r32_elems, (size_t)B * q.cout * Tp);
+      } else {
+        for (int j = 0; j < QASR_MAX_OUTS; ++j)
+          if (q.outs[j].tensor >= 0 && q.outs[j].mode != 1) ok = false;
+        if (!ok) continue;
+        e->utt[oi] = 1;
+      }
+    }
+  if (r32_elems) HIPCHK(hipMalloc((void**)&e->r32, r32_elems * sizeof(int32_t)));
   e->B = B;
   e->T0 = T0;
   return QASR_OK;
@@ -266,6 +302,8 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
   e->debug = (debug & 1) != 0;
   e->fuse = getenv("QASR_NO_FUSE") == nullptr;
   e->legacy_pw = getenv("QASR_LEGACY_PW") != nullptr;
+  // whole-utterance kernels (k_utt) are opt-in: bit 2 of `debug` or QASR_UTT=1 (throughput experiments)
+  e->use_utt = (debug & 4) != 0 || getenv("QASR_UTT") != nullptr;
   e->timing = (debug & 3) != 0;
   e->blob.assign((const uint8_t*)blob, (const uint8_t*)blob + n);
   e->h = h;
@@ -378,7 +416,35 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
           p.dilation = 1;
           p.pw_unsigned = tin.d.dtype == QASR_DT_U8;
         }
-        launch_sep(s, p);
+        if (e->utt[oi] == 1) {
+          launch_utt(s, p, 0);
+        } else if (e->utt[oi] == 2) {
+          // res_act as two whole-utterance launches: the residual 1x1 conv leaves rint(acc * M) in int32,
+          // the separable layer adds it in its epilogue (same arithmetic as the single-launch k_sep form)
+          SepP r{};
+          const PaneP& pn = p.panes[0];
+          r.x = pn.x;
+          r.w = pn.w;
+          r.bias = pn.bias;
+          r.cin = pn.cin;
+          r.cin_pad = pn.cin_pad;
+          r.pw_unsigned = pn.x_unsigned;
+          r.K = 0;
+          r.dilation = 1;
+          r.e = p.e;
+          r.e.sb = pn.sb;
+          r.e.m_main = pn.m;
+          r.e.acc_dbg = pn.acc_dbg;
+          r.e.n_outs = 1;
+          r.e.outs[0].ptr = e->r32;
+          r.e.outs[0].mode = 3;
+          launch_utt(s, r, 1);
+          p.r32 = e->r32;
+          p.n_panes = 0;
+          launch_utt(s, p, 2);
+        } else {
+          launch_sep(s, p);
+        }
         break;
       }
       PwP p{};

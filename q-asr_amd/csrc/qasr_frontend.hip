@@ -30,17 +30,23 @@ __device__ __forceinline__ float sample(const float* x, int S, int i, float pree
 // The mel matrix is sparse (each triangular filter covers a short run of FFT bins): k_melrange finds the non-zero
 // run of every filter once per call, k_mel then multiplies only inside it.  Skipped terms are fma(0, P, acc) = acc,
 // so the float result is identical to the dense product.
-__global__ void k_melrange(const float* __restrict__ fb, int n_mels, int* __restrict__ ranges) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= n_mels) return;
+__global__ void __launch_bounds__(64) k_melrange(const float* __restrict__ fb, int n_mels, int* __restrict__ ranges) {
+  const int m = blockIdx.x, lane = threadIdx.x;           // one wave per filter, coalesced row read
   int lo = NBIN, hi = 0;
-  for (int k = 0; k < NBIN; ++k)
+  for (int k = lane; k < NBIN; k += 64)
     if (fb[(size_t)m * NBIN + k] != 0.f) {
       lo = min(lo, k);
-      hi = k + 1;
+      hi = max(hi, k + 1);
     }
-  ranges[2 * m] = min(lo, hi);
-  ranges[2 * m + 1] = hi;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, __shfl_xor(lo, o));
+    hi = max(hi, __shfl_xor(hi, o));
+  }
+  if (lane == 0) {
+    ranges[2 * m] = min(lo, hi);
+    ranges[2 * m + 1] = hi;
+  }
 }
 
 // every wave owns its FFT buffers, so stages are separated by a wave-level fence instead of a work-group barrier:
@@ -177,7 +183,7 @@ int qasr_frontend_mel(void* stream, const float* audio, const int32_t* audio_len
   hipStream_t s = (hipStream_t)stream;
   const int frames = B * n_frames;
   int* ranges = (int*)workspace;
-  hipLaunchKernelGGL(qasr::k_melrange, dim3((n_mels + 63) / 64), dim3(64), 0, s, fb, n_mels, ranges);
+  hipLaunchKernelGGL(qasr::k_melrange, dim3(n_mels), dim3(64), 0, s, fb, n_mels, ranges);
   const int per_wg = 4 * MEL_FPW;
   hipLaunchKernelGGL(qasr::k_mel, dim3((frames + per_wg - 1) / per_wg), dim3(256), 0, s, audio, B, S, fb, window, ranges,
                      n_mels, preemph, n_frames, T_pad, feats);

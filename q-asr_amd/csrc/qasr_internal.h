@@ -82,6 +82,7 @@ struct SepP {             // fused separable layer: depthwise stencil -> QuantAc
   const int8_t* w;        // [cout_pad][cin_pad]
   const int32_t* bias;    // [cout_pad]
   int cin, cin_pad, pw_unsigned, n_panes;
+  const int32_t* r32;     // k_utt EP_ADD32: res_act operand rint(acc_res * M_res) of the block's residual conv
   long long* prof;        // diagnostics: s_memtime stamps of work-group (0,0,0), wave 0 (qasr_debug_prof)
   PaneP panes[QASR_MAX_PANES];
   EpiP e;
@@ -113,6 +114,8 @@ void launch_pw(hipStream_t s, const PwP& p);
 void launch_dense(hipStream_t s, const DenseP& p);
 bool sep_supported(int K, int dilation);
 void launch_sep(hipStream_t s, const SepP& p);
+bool utt_supported(int K, int dilation, int Tp, int cin_pad, int cin);
+void launch_utt(hipStream_t s, const SepP& p, int ep);   // ep: 0 plain, 1 rq32 (residual conv), 2 add32 (res_act)
 void launch_requant(hipStream_t s, const RequantP& p);
 void launch_logsoftmax(hipStream_t s, const float* logits, float* logp, int32_t* tokens, int rows, int ncls);
 void launch_lens(hipStream_t s, const int32_t* lens_in, int32_t* lens_all, const qasr_domain_desc* doms,

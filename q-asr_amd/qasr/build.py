@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), 'csrc')
 LIB = os.path.join(HERE, 'libqasr_hip.so')
-SOURCES = ['qasr_kernels.hip', 'qasr_sep.hip', 'qasr_engine.hip', 'qasr_frontend.hip']
+SOURCES = ['qasr_kernels.hip', 'qasr_sep.hip', 'qasr_utt.hip', 'qasr_engine.hip', 'qasr_frontend.hip']
 
 
 def _stale():

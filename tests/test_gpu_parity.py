@@ -112,12 +112,12 @@ def test_requant_exact_z_golden(eng, golden_dir):
 
 
 # ---------------------------------------------------------------------------------- networks
-def _run_engine(eng, golden_dir, name, debug=True):
+def _run_engine(eng, golden_dir, name, debug=True, whole_utterance=False):
     d, meta = _load(golden_dir, name)
     cfg = _cfg(name)
     sd = synth.make_state_dict(cfg, meta['seed'])
     blob, pm = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], meta['wbit'], meta['abit'])
-    e = eng.Engine(blob, 0, debug=debug)
+    e = eng.Engine(blob, 0, debug=debug, whole_utterance=whole_utterance)
     x = synth.make_features(meta['batch'], cfg.feat_in, meta['frames'], meta['seed'])
     logp, tokens, enc_len = e.forward(torch.from_numpy(x).cuda(), torch.tensor(meta['lengths']))
     torch.cuda.synchronize()
@@ -133,9 +133,10 @@ def _site_dims(cfg):
     return dims
 
 
+@pytest.mark.parametrize('whole_utterance', [False, True], ids=['k_sep', 'k_utt'])
 @pytest.mark.parametrize('name', ['net_miniq_w8a8', 'net_miniq_w8a8_pct', 'net_miniq_w6a6', 'net_minij_w8a8'])
-def test_mini_net_every_accumulator(eng, golden_dir, name):
-    d, meta, cfg, pm, e, logp, tokens, enc_len = _run_engine(eng, golden_dir, name)
+def test_mini_net_every_accumulator(eng, golden_dir, name, whole_utterance):
+    d, meta, cfg, pm, e, logp, tokens, enc_len = _run_engine(eng, golden_dir, name, whole_utterance=whole_utterance)
     couts = _site_dims(cfg)
     for i, (op, pane) in enumerate(pm['sites']):
         want = d[f'acc_{i}']                               # rint(conv_int) of the reference itself
@@ -147,9 +148,10 @@ def test_mini_net_every_accumulator(eng, golden_dir, name):
     e.close()
 
 
+@pytest.mark.parametrize('whole_utterance', [False, True], ids=['k_sep', 'k_utt'])
 @pytest.mark.parametrize('name', ['net_quartznet_w8a8', 'net_quartznet_w6a6', 'net_jasper_w8a8'])
-def test_full_net_checksums(eng, golden_dir, name):
-    d, meta, cfg, pm, e, logp, tokens, enc_len = _run_engine(eng, golden_dir, name)
+def test_full_net_checksums(eng, golden_dir, name, whole_utterance):
+    d, meta, cfg, pm, e, logp, tokens, enc_len = _run_engine(eng, golden_dir, name, whole_utterance=whole_utterance)
     couts = _site_dims(cfg)
     T_out = d['tokens'].shape[1]
     for i, (op, pane) in enumerate(pm['sites']):
@@ -176,6 +178,7 @@ def test_bench_size_properties(eng, golden_dir):
     sd = synth.make_state_dict(cfg, meta['seed'])
     blob, _ = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
     e = eng.Engine(blob, 0, debug=False)
+    eu = eng.Engine(blob, 0, debug=False, whole_utterance=True)
     B, T = 32, 500
     x = torch.from_numpy(synth.make_features(B, 64, T, 11)).cuda()
     lens = torch.tensor([T - 7 * (i % 9) for i in range(B)])
@@ -183,6 +186,9 @@ def test_bench_size_properties(eng, golden_dir):
     tk1, el1, lp1 = tk1.cpu().numpy(), el1.cpu().numpy(), lp1.cpu().numpy()
     lp2, tk2, _ = e.forward(x, lens)
     assert np.array_equal(tk1, tk2.cpu().numpy()) and np.array_equal(lp1, lp2.cpu().numpy())
+    lpu, tku, _ = eu.forward(x, lens)                          # whole-utterance kernels: identical integers
+    assert np.array_equal(tk1, tku.cpu().numpy()) and np.array_equal(lp1, lpu.cpu().numpy())
+    eu.close()
     assert np.array_equal(el1, (lens.numpy() + 1) // 2)
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
     _, tk3, _ = e.forward(x[perm].contiguous(), lens[perm])
