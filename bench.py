@@ -10,7 +10,7 @@ shard (weak scaling); rank 0 calibrates + packs the model and broadcasts the pac
 and each step ends with an RCCL gather of the greedy tokens to rank 0.
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the launch stream (each op
-replayed 20x between one event pair) for the dominant kernel class, the int8-MFMA pointwise GEMM k_pw; `cpu_baseline`
+replayed 20x between one event pair) for the kernel instantiation with the largest share of the step (a k_sep<K,...> fused separable layer); `cpu_baseline`
 times the reference's fake-quant CPU op sequence (oracle/fakequant_torch.py) on the host cores (N=1 only).
 """
 import argparse
@@ -32,6 +32,8 @@ import torch  # noqa: E402
 
 PEAK_INT8_OPS = 256 * 4 * 2048 * 2.4e9       # 256 CUs x 4 SIMDs x 1024 MAC/clk (v_mfma_i32_32x32x32_i8) x 2.4 GHz
 PEAK_HBM = 8.0e12
+# HBM bytes per dispatch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE), by kernel
+TRAFFIC_BYTES = {}
 MODEL = 'QuartzNet15x5Base-En'
 BATCH, SAMPLES, FRAMES = 32, 80000, 500
 
@@ -70,6 +72,66 @@ def algorithmic_work(cfg, B, T_out):
                 mfma += 2 * macs
     mfma += 2 * B * T_out * cfg.blocks[-1].filters * (cfg.num_classes + 1)
     return mfma, dw, dw_bytes
+
+
+def dominant_kernel_roofline(eng, cfg, meta, ms, B, T):
+    """Roofline entry for the kernel instantiation with the largest summed time per step.
+
+    Algorithmic work per launch (2 ops per MAC; a fused dw->pw layer reads the depthwise input once,
+    writes the pointwise output once, reads its weights once), T = valid output frames.  The bound is whichever of
+    t_MFMA = ops / peak_int8 and t_HBM = bytes / 8 TB/s is larger for that work."""
+    import collections
+    from qasr import topology
+    labels = eng.op_labels()
+    plan = [s for ss in topology.conv_plan(cfg) for s in ss]
+    main, panes = {}, collections.defaultdict(list)
+    for i, (op, pane) in enumerate(meta['sites']):
+        if i < len(plan):
+            (panes[op].append(plan[i]) if pane >= 0 else main.__setitem__(op, plan[i]))
+    groups = collections.defaultdict(list)
+    for oi, lab in enumerate(labels):
+        if not lab.startswith('('):
+            groups[lab].append(oi)
+    tot = {lab: sum(ms[o] for o in ops) for lab, ops in groups.items()}
+    lab = max(tot, key=tot.get)
+    ops_l = groups[lab]
+    mfma = vdot = byts = 0
+    for oi in ops_l:
+        s = main.get(oi)
+        if s is None:                                            # decoder / non-conv op
+            continue
+        cin = s.cin // s.groups
+        if s.role == 'dw':
+            vdot += 2 * B * T * s.cout * s.kernel
+        else:
+            mfma += 2 * B * T * s.cout * cin * s.kernel
+        byts += B * T * (s.cin + s.cout) + s.cout * cin * s.kernel
+        for r in panes.get(oi, []):
+            mfma += 2 * B * T * r.cout * r.cin
+            byts += B * T * r.cin + r.cout * r.cin
+        if oi > 0 and labels[oi - 1].startswith('(fused') and (oi - 1) in main:
+            d = main[oi - 1]                                     # depthwise stage inside this launch
+            vdot += 2 * B * T * d.cout * d.kernel
+            byts += d.cout * d.kernel                            # its input replaces the pw input already counted
+    n = len(ops_l)
+    t = tot[lab] * 1e-3 / n                                      # s per launch
+    t_mfma, t_hbm = mfma / n / PEAK_INT8_OPS, byts / n / PEAK_HBM
+    serial = float(sum(ms))
+    out = {'kernel': 'qasr::' + lab, 'launches_per_step': n, 'avg_launch_us': 1e6 * t,
+           'share_of_step_device_time': tot[lab] / serial,
+           'algorithmic_bytes_per_launch': byts / n, 'mfma_ops_per_launch': mfma / n,
+           'valu_dot4_ops_per_launch': vdot / n, 'traffic': TRAFFIC_BYTES.get(lab)}
+    if t_hbm >= t_mfma:
+        out.update(bound='hbm', achieved=byts / n / t / 1e9, peak=PEAK_HBM / 1e9, unit='GB/s', frac=t_hbm / t)
+    else:
+        out.update(bound='mfma', achieved=mfma / n / t / 1e12, peak=PEAK_INT8_OPS / 1e12, unit='TFLOP/s', frac=t_mfma / t)
+    out['other'] = {
+        'mfma_frac': t_mfma / t, 'hbm_frac': t_hbm / t, 'all_ops_ms_per_step_serial': serial,
+        'per_kernel_ms_per_step': {k: round(v, 4) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])},
+        'timing': 'each op replayed 20x between one HIP event pair on the launch stream, no other work in flight',
+        'traffic_source': 'rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes, per '
+                          'dispatch average (profiles/); null = not collected for this instantiation'}
+    return out
 
 
 def build_model(device):
@@ -197,29 +259,14 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel class (k_pw), HIP events per op on the launch stream -------------
+        # ---- roofline of the dominant kernel, HIP events on the launch stream ---------------------------------
         # every op is replayed 20x back to back between one HIP event pair on the launch stream
         # (qasr_engine_time_ops); buffers hold the real activations of the last timed step
         ms = eng.time_ops(reps=20).astype(np.float64)
-        kinds = np.array(meta['kinds'])
-        mfma_ops, dw_ops, dw_bytes = algorithmic_work(cfg, BATCH, T_out)
-        # k_sep launches = every PW op (a fused depthwise stage reports 0 ms on its own op slot)
-        t_sep = float(ms[kinds == 2].sum()) * 1e-3
-        t_dw = float(ms[kinds == 1].sum()) * 1e-3                # depthwise layers that still run stand-alone
-        n_sep = int((kinds == 2).sum())
-        n_fused = int(((kinds == 1) & (ms < 1e-3)).sum())
-        achieved = mfma_ops / t_sep                              # MFMA-class ops only: the fused dw taps run on VALU
-        result['roofline'] = {
-            'kernel': 'k_sep (fused depthwise stencil -> int8 MFMA 1x1 GEMM -> requant / res_act epilogue)',
-            'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': PEAK_INT8_OPS / 1e12, 'unit': 'TFLOP/s',
-            'frac': achieved / PEAK_INT8_OPS, 'traffic': None,
-            'launches_per_step': n_sep, 'avg_launch_us': 1e6 * t_sep / n_sep, 'ops_per_launch': mfma_ops / n_sep,
-            'other': {'fused_depthwise_layers': n_fused, 'depthwise_gop_inside_k_sep': dw_ops / 1e9,
-                      'standalone_dw_ms_per_step': 1e3 * t_dw, 'k_sep_ms_per_step': 1e3 * t_sep,
-                      'all_ops_ms_per_step_serial': float(ms.sum()),
-                      'timing': 'each op replayed 20x between one HIP event pair on the launch stream, no other work '
-                                'in flight'},
-        }
+        result['roofline'] = dominant_kernel_roofline(eng, cfg, meta, ms, BATCH, FRAMES // 2)
+        mfma_ops, dw_ops, _ = algorithmic_work(cfg, BATCH, FRAMES // 2)
+        result['roofline']['other'].update(step_mfma_class_gop=mfma_ops / 1e9, step_depthwise_gop=dw_ops / 1e9,
+                                           step_mfma_class_top_s=mfma_ops / (dt / args.steps) / 1e12)
 
         # ---- CPU baseline: the reference's fake-quant op sequence on this host's cores (N=1 only) --------------
         if world == 1 and not args.no_cpu_baseline:

@@ -155,6 +155,9 @@ int qasr_engine_last_op_ms(qasr_engine* e, float* ms_per_op, int n_ops);
 /* Roofline hook: after a forward, replay each op `reps` times back to back between one pair of HIP events on
  * `stream` and return the average duration per launch in ms (synchronises). */
 int qasr_engine_time_ops(qasr_engine* e, void* stream, int reps, float* ms_per_launch, int n_ops);
+/* Name of the kernel instantiation op `op` is routed to, with its template arguments as rocprofv3 prints them
+ * ("k_sep<75, 1, 1, false>", "k_dw", ...); ops executed inside the next op's launch report "(fused ...)". */
+int qasr_engine_op_label(qasr_engine* e, int op, char* buf, size_t cap);
 /* Re-enqueue a single op of the last forward's plan (diagnostics / profiling of one layer). */
 int qasr_engine_run_op(qasr_engine* e, void* stream, int op);
 

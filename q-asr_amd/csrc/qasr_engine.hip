@@ -117,6 +117,21 @@ static int build_plan(qasr_engine* e, int B, int T0) {
     t.bytes = (t.d.dtype == QASR_DT_F32) ? (size_t)B * t.T * t.d.channels * 4 : (size_t)B * t.d.channels * t.Tp * dt_size(t.d.dtype);
     t.bytes = (t.bytes + 255) / 256 * 256;
   }
+  // fusion plan first: it moves the point where a depthwise input is read to the following launch
+  e->fused_dw.assign(h.n_ops, -1);
+  e->skip.assign(h.n_ops, 0);
+  if (e->fuse)
+    for (uint32_t oi = 0; oi + 1 < h.n_ops; ++oi) {
+      const qasr_op_desc& d = e->ops[oi];
+      const qasr_op_desc& q = e->ops[oi + 1];
+      if (d.kind != QASR_OP_DW || q.kind != QASR_OP_PW) continue;
+      const uint32_t same_pad = d.dilation > 1 ? (d.dilation * d.kernel) / 2 - 1 : d.kernel / 2;
+      if (d.stride != 1 || d.padding != same_pad || !(d.kernel & 1) || !sep_supported((int)d.kernel, (int)d.dilation)) continue;
+      if (d.outs[1].tensor >= 0 || d.outs[0].mode != 1 || q.in != d.outs[0].tensor) continue;
+      if (e->tdesc[d.outs[0].tensor].last_use != (int)oi + 1 || (d.flags & QASR_F_EXACT_Z)) continue;
+      e->fused_dw[oi + 1] = (int)oi;
+      e->skip[oi] = 1;
+    }
   // greedy arena: a slot is reused once its tensor's last reader has been enqueued (stream order makes that safe)
   std::vector<int> free_slots;
   auto acquire = [&](TensorRT& t) -> int {
@@ -146,7 +161,11 @@ static int build_plan(qasr_engine* e, int B, int T0) {
       if (e->tens[i].d.producer == (int)oi && acquire(e->tens[i]) < 0) return fail(QASR_ERR_HIP, "hipMalloc failed (arena)");
     for (uint32_t i = 1; i < h.n_tensors; ++i) {
       TensorRT& t = e->tens[i];
-      bool dead_after = t.d.producer <= (int)oi && t.slot >= 0 && std::max(t.d.last_use, t.d.producer) == (int)oi;
+      // a depthwise op fused into the next op's launch reads its input THERE: the input must outlive that launch,
+      // or the fused kernel's output could be planned into the very buffer its halo reads come from
+      int last = std::max(t.d.last_use, t.d.producer);
+      if (last >= 0 && last + 1 < (int)h.n_ops && e->skip[last]) last += 1;
+      bool dead_after = t.d.producer <= (int)oi && t.slot >= 0 && last == (int)oi;
       if (dead_after && !e->debug) free_slots.push_back(t.slot);
     }
   }
@@ -171,20 +190,6 @@ static int build_plan(qasr_engine* e, int B, int T0) {
     e->ev.resize(h.n_ops + 1);
     for (auto& v : e->ev) HIPCHK(hipEventCreate(&v));
   }
-  e->fused_dw.assign(h.n_ops, -1);
-  e->skip.assign(h.n_ops, 0);
-  if (e->fuse)
-    for (uint32_t oi = 0; oi + 1 < h.n_ops; ++oi) {
-      const qasr_op_desc& d = e->ops[oi];
-      const qasr_op_desc& q = e->ops[oi + 1];
-      if (d.kind != QASR_OP_DW || q.kind != QASR_OP_PW) continue;
-      const uint32_t same_pad = d.dilation > 1 ? (d.dilation * d.kernel) / 2 - 1 : d.kernel / 2;
-      if (d.stride != 1 || d.padding != same_pad || !(d.kernel & 1) || !sep_supported((int)d.kernel, (int)d.dilation)) continue;
-      if (d.outs[1].tensor >= 0 || d.outs[0].mode != 1 || q.in != d.outs[0].tensor) continue;
-      if (e->tdesc[d.outs[0].tensor].last_use != (int)oi + 1 || (d.flags & QASR_F_EXACT_Z)) continue;
-      e->fused_dw[oi + 1] = (int)oi;
-      e->skip[oi] = 1;
-    }
   e->utt.assign(h.n_ops, 0);
   size_t r32_elems = 0;
   if (e->use_utt && e->fuse)
@@ -345,6 +350,40 @@ int qasr_engine_out_frames(const qasr_engine* e, int T) {
   return dT[e->tdesc[last.in].domain];
 }
 
+// parameter block of the fused separable-layer kernels (k_sep / k_utt) for PW op `oi`
+static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
+  const qasr_op_desc& op = e->ops[oi];
+  const TensorRT& tin = e->tens[op.in];
+  p.w = dev_at<int8_t>(e, op.w_off);
+  p.bias = dev_at<int32_t>(e, op.bias_off);
+  p.cin = (int)op.cin;
+  p.cin_pad = rup(p.cin, 128);
+  p.n_panes = (int)op.n_panes;
+  fill_panes(e, oi, op, p.panes);
+  fill_epi(e, oi, op, p.e);
+  const int di = e->fused_dw[oi];
+  if (di >= 0) {
+    const qasr_op_desc& d = e->ops[di];
+    const TensorRT& din = e->tens[d.in];
+    p.x = (const int8_t*)din.ptr;
+    p.wdw = dev_at<int8_t>(e, d.w_off);
+    p.bias_dw = dev_at<int32_t>(e, d.bias_off);
+    p.m_dw = dev_at<double>(e, d.outs[0].m_off);
+    p.dw_acc_dbg = (e->debug && !e->acc_dbg[di].empty()) ? e->acc_dbg[di][0] : nullptr;
+    p.dw_lo = d.outs[0].lo;
+    p.dw_hi = d.outs[0].hi;
+    p.K = (int)d.kernel;
+    p.dilation = (int)d.dilation;
+    p.x_unsigned = din.d.dtype == QASR_DT_U8;
+    p.pw_unsigned = 0;
+  } else {
+    p.x = (const int8_t*)tin.ptr;
+    p.K = 0;
+    p.dilation = 1;
+    p.pw_unsigned = tin.d.dtype == QASR_DT_U8;
+  }
+}
+
 static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, int32_t* tokens, int32_t* lens_out) {
   const qasr_op_desc& op = e->ops[oi];
   const int B = e->B;
@@ -388,34 +427,7 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
     case QASR_OP_PW: {
       if (!e->legacy_pw || e->fused_dw[oi] >= 0) {
         SepP p{};
-        p.w = dev_at<int8_t>(e, op.w_off);
-        p.bias = dev_at<int32_t>(e, op.bias_off);
-        p.cin = (int)op.cin;
-        p.cin_pad = rup(p.cin, 128);
-        p.n_panes = (int)op.n_panes;
-        fill_panes(e, oi, op, p.panes);
-        fill_epi(e, oi, op, p.e);
-        const int di = e->fused_dw[oi];
-        if (di >= 0) {
-          const qasr_op_desc& d = e->ops[di];
-          const TensorRT& din = e->tens[d.in];
-          p.x = (const int8_t*)din.ptr;
-          p.wdw = dev_at<int8_t>(e, d.w_off);
-          p.bias_dw = dev_at<int32_t>(e, d.bias_off);
-          p.m_dw = dev_at<double>(e, d.outs[0].m_off);
-          p.dw_acc_dbg = (e->debug && !e->acc_dbg[di].empty()) ? e->acc_dbg[di][0] : nullptr;
-          p.dw_lo = d.outs[0].lo;
-          p.dw_hi = d.outs[0].hi;
-          p.K = (int)d.kernel;
-          p.dilation = (int)d.dilation;
-          p.x_unsigned = din.d.dtype == QASR_DT_U8;
-          p.pw_unsigned = 0;
-        } else {
-          p.x = (const int8_t*)tin.ptr;
-          p.K = 0;
-          p.dilation = 1;
-          p.pw_unsigned = tin.d.dtype == QASR_DT_U8;
-        }
+        build_sep(e, oi, p);
         if (e->utt[oi] == 1) {
           launch_utt(s, p, 0);
         } else if (e->utt[oi] == 2) {
@@ -556,6 +568,36 @@ int qasr_engine_time_ops(qasr_engine* e, void* stream, int reps, float* ms_per_l
   }
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
+  return QASR_OK;
+}
+
+int qasr_engine_op_label(qasr_engine* e, int op, char* buf, size_t cap) {
+  if (!e || !buf || cap < 8 || op < 0 || op >= (int)e->h.n_ops) return fail(QASR_ERR_ARG, "op_label: bad argument");
+  const qasr_op_desc& d = e->ops[op];
+  const char* name = "?";
+  if (e->skip[op]) name = "(fused into the next op)";
+  else switch (d.kind) {
+    case QASR_OP_QUANT_IN: name = "k_quant_in"; break;
+    case QASR_OP_DW: name = "k_dw"; break;
+    case QASR_OP_DENSE: name = "k_dense"; break;
+    case QASR_OP_LOGSOFTMAX: name = "k_logsoftmax"; break;
+    case QASR_OP_REQUANT: name = "k_requant"; break;
+    case QASR_OP_PW:
+      if (e->legacy_pw && e->fused_dw[op] < 0) { name = "k_pw"; break; }
+      if (e->utt[op]) {
+        const int di = e->fused_dw[op];
+        snprintf(buf, cap, "k_utt<%d>%s", di >= 0 ? (int)e->ops[di].kernel : 0, e->utt[op] == 2 ? " x2 (rq32 + add32)" : "");
+        return QASR_OK;
+      }
+      {
+        SepP p{};
+        build_sep(e, (uint32_t)op, p);
+        sep_kernel_label(p, buf, cap);
+        return QASR_OK;
+      }
+    default: break;
+  }
+  snprintf(buf, cap, "%s", name);
   return QASR_OK;
 }
 

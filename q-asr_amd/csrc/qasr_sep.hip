@@ -13,6 +13,7 @@
 //      the weight fragments coming straight from L2 (each is used by exactly one wave);
 //   4. epilogue in registers (per-channel parameters are per-lane scalars), LDS-staged 16-B stores.
 #include <algorithm>
+#include <cstdio>
 
 #include "qasr_device.h"
 
@@ -514,6 +515,12 @@ static void launch_sep_k(hipStream_t s, const SepP& p) {
     else if (ep == EP_RESADD1) launch_sep_v<K, DIL, EP_RESADD1, false>(s, p);
     else launch_sep_v<K, DIL, EP_GENERIC, false>(s, p);
   }
+}
+
+// template arguments of the k_sep instantiation launch_sep picks for `p` (as rocprofv3 prints them)
+void sep_kernel_label(const SepP& p, char* buf, size_t cap) {
+  const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
+  snprintf(buf, cap, "k_sep<%d, %d, %d, %s>", p.K, p.K > 0 ? p.dilation : 1, sep_epilogue_class(p), dbg ? "true" : "false");
 }
 
 void launch_sep(hipStream_t s, const SepP& p) {

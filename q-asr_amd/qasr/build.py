@@ -24,7 +24,8 @@ def build_native(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB] + srcs
+    extra = os.environ.get('QASR_HIPCC_FLAGS', '').split()          # experiments: -DSEP_MIN_WAVES=4 ...
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB] + extra + srcs
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -7,11 +7,11 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libqasr_hip.so')
+LIB_PATH = os.environ.get('QASR_LIB', os.path.join(HERE, 'libqasr_hip.so'))   # QASR_LIB: A/B builds in one run
 
 SYMBOLS = ['qasr_engine_create', 'qasr_engine_destroy', 'qasr_engine_forward', 'qasr_engine_out_frames',
            'qasr_engine_num_ops', 'qasr_engine_read_acc', 'qasr_engine_read_tensor', 'qasr_engine_last_op_ms',
-           'qasr_engine_time_ops', 'qasr_engine_run_op',
+           'qasr_engine_time_ops', 'qasr_engine_run_op', 'qasr_engine_op_label',
            'qasr_frontend_mel', 'qasr_frontend_frames', 'qasr_frontend_workspace_bytes', 'qasr_pw_conv_acc',
            'qasr_dw_conv_acc', 'qasr_requant', 'qasr_debug_prof', 'qasr_last_error', 'qasr_version']
 
@@ -43,6 +43,7 @@ def load_library():
     lib.qasr_engine_last_op_ms.argtypes = [vp, vp, i32]
     lib.qasr_engine_time_ops.argtypes = [vp, vp, i32, vp, i32]
     lib.qasr_engine_run_op.argtypes = [vp, vp, i32]
+    lib.qasr_engine_op_label.argtypes = [vp, i32, C.c_char_p, sz]
     lib.qasr_frontend_mel.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, C.c_float, i32, vp, vp, vp, sz]
     lib.qasr_frontend_frames.argtypes = [i32, i32]
     lib.qasr_frontend_workspace_bytes.argtypes = [i32, i32, i32]
@@ -144,6 +145,15 @@ class Engine:
         _check(self.lib.qasr_engine_time_ops(self._h, _stream_ptr(stream), reps, ms.ctypes.data_as(C.c_void_p),
                                              self.n_ops), 'qasr_engine_time_ops')
         return ms
+
+    def op_labels(self):
+        """kernel instantiation every op is routed to (names as rocprofv3 prints them)"""
+        out = []
+        buf = C.create_string_buffer(96)
+        for op in range(self.n_ops):
+            _check(self.lib.qasr_engine_op_label(self._h, op, buf, 96), 'qasr_engine_op_label')
+            out.append(buf.value.decode())
+        return out
 
     def run_op(self, op, stream=None):
         _check(self.lib.qasr_engine_run_op(self._h, _stream_ptr(stream), int(op)), 'qasr_engine_run_op')
