@@ -32,8 +32,28 @@ import torch  # noqa: E402
 
 PEAK_INT8_OPS = 256 * 4 * 2048 * 2.4e9       # 256 CUs x 4 SIMDs x 1024 MAC/clk (v_mfma_i32_32x32x32_i8) x 2.4 GHz
 PEAK_HBM = 8.0e12
-# HBM bytes per dispatch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE), by kernel
-TRAFFIC_BYTES = {}
+
+
+def pmc_traffic():
+    """HBM bytes per dispatch by kernel, from the newest PMC summaries committed under profiles/ (written by
+    profiles/collect.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, KB per dispatch).  gfx950 tallies a
+    128-B read request as 64 B, so FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact."""
+    import glob
+    import re
+    out, src = {}, None
+    fs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_FETCH_SIZE.txt')))
+    if not fs:
+        return out, src
+    src = os.path.basename(fs[-1]).replace('_pmc_FETCH_SIZE.txt', '')
+    for name, mult in (('FETCH_SIZE', 2.0), ('WRITE_SIZE', 1.0)):
+        path = os.path.join(ROOT, 'profiles', f'{src}_pmc_{name}.txt')
+        if not os.path.exists(path):
+            return {}, None
+        for line in open(path):
+            m = re.match(r'\s*(?:void )?qasr::(.+?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$', line)
+            if m:
+                out[m.group(1)] = out.get(m.group(1), 0.0) + mult * 1024.0 * float(m.group(4))
+    return out, src
 MODEL = 'QuartzNet15x5Base-En'
 BATCH, SAMPLES, FRAMES = 32, 80000, 500
 
@@ -114,13 +134,14 @@ def dominant_kernel_roofline(eng, cfg, meta, ms, B, T):
             vdot += 2 * B * T * d.cout * d.kernel
             byts += d.cout * d.kernel                            # its input replaces the pw input already counted
     n = len(ops_l)
+    traffic, traffic_src = pmc_traffic()
     t = tot[lab] * 1e-3 / n                                      # s per launch
     t_mfma, t_hbm = mfma / n / PEAK_INT8_OPS, byts / n / PEAK_HBM
     serial = float(sum(ms))
     out = {'kernel': 'qasr::' + lab, 'launches_per_step': n, 'avg_launch_us': 1e6 * t,
            'share_of_step_device_time': tot[lab] / serial,
            'algorithmic_bytes_per_launch': byts / n, 'mfma_ops_per_launch': mfma / n,
-           'valu_dot4_ops_per_launch': vdot / n, 'traffic': TRAFFIC_BYTES.get(lab)}
+           'valu_dot4_ops_per_launch': vdot / n, 'traffic': traffic.get(lab)}
     if t_hbm >= t_mfma:
         out.update(bound='hbm', achieved=byts / n / t / 1e9, peak=PEAK_HBM / 1e9, unit='GB/s', frac=t_hbm / t)
     else:
@@ -130,7 +151,7 @@ def dominant_kernel_roofline(eng, cfg, meta, ms, B, T):
         'per_kernel_ms_per_step': {k: round(v, 4) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])},
         'timing': 'each op replayed 20x between one HIP event pair on the launch stream, no other work in flight',
         'traffic_source': 'rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes, per '
-                          'dispatch average (profiles/); null = not collected for this instantiation'}
+                          f'dispatch average, bytes (profiles/{traffic_src}_pmc_*.txt); null = not collected'}
     return out
 
 
@@ -234,12 +255,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    last = []
     for i in range(args.steps):
         tokens = step(i)
+        last = (last + [tokens])[-S:]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # every step decodes the same batch: the steps that were in flight together must agree bit for bit
+    if not all(torch.equal(t_, last[0]) for t_ in last):
+        raise SystemExit('bench: concurrent steps produced different tokens')
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -10,7 +10,9 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 50 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o p -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_rocprof.err || exit 2
+# kernel durations: one step in flight (what bench.py's HIP-event roofline pass measures), then the default 4 in flight
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o p -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --streams 1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_rocprof.err || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof4_$TAG -o p -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof_4inflight.json 2>> $OUT/${TAG}_rocprof.err || exit 2
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_${TAG}_$C -o c -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --streams 1 > $OUT/pmc_${TAG}_$C.log 2>&1 || exit 3
 done
@@ -18,10 +20,11 @@ python3 - "$TAG" "$OUT" <<'PY'
 import collections, csv, glob, os, sys
 tag, out = sys.argv[1:3]
 # kernel stats filtered to this repo's kernels
-for f in glob.glob(os.path.join(out, 'prof_' + tag, '**', '*kernel_stats.csv'), recursive=True):
-    rows = list(csv.reader(open(f)))
-    keep = [rows[0]] + [r for r in rows[1:] if 'qasr::' in r[0]]
-    csv.writer(open(os.path.join(out, tag + '_kernel_stats.csv'), 'w')).writerows(keep)
+for d, suffix in (('prof_', ''), ('prof4_', '_4inflight')):
+    for f in glob.glob(os.path.join(out, d + tag, '**', '*kernel_stats.csv'), recursive=True):
+        rows = list(csv.reader(open(f)))
+        keep = [rows[0]] + [r for r in rows[1:] if 'qasr::' in r[0]]
+        csv.writer(open(os.path.join(out, tag + '_kernel_stats' + suffix + '.csv'), 'w')).writerows(keep)
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for f in glob.glob(os.path.join(out, f'pmc_{tag}_{c}', '**', '*counter_collection.csv'), recursive=True):
@@ -36,5 +39,5 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
             fh.write(f'{k:70s} {n:6d} {v:14.1f} {v / n:12.2f}\n')
 PY
 # keep the merged directory small (gpurun_out is capped at 64 MiB)
-rm -rf $OUT/prof_$TAG $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE
+rm -rf $OUT/prof_$TAG $OUT/prof4_$TAG $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE
 ls -la $OUT | grep $TAG
