@@ -199,13 +199,22 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the integer engine has no CPU fallback')
+    # QASR_BENCH_BACKEND=gloo rehearses the N>1 control flow on a one-GPU box: every rank uses GPU 0 and the two
+    # exchange steps go through host memory.  The measured configuration is always nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get('QASR_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    comm_dev = dev if backend == 'nccl' else torch.device('cpu')
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)         # "nccl" is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)     # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from qasr import engine, synth, topology
     engine.load_library()
@@ -218,8 +227,8 @@ def main():
     if rank == 0:
         blob, meta, fb, window, amin, amax = build_model(dev)
     if world > 1:
-        blob = qdist.broadcast_bytes(blob, 0, dev)
-        fb, window = qdist.broadcast_tensors([fb, window], 0, dev)
+        blob = qdist.broadcast_bytes(blob, 0, comm_dev)
+        fb, window = qdist.broadcast_tensors([fb, window], 0, comm_dev)
     fb, window = fb.to(dev), window.to(dev)
     # throughput mode: consecutive steps are independent batches, so S of them are kept in flight, each on its own
     # HIP stream with its own engine arena (kernels of different steps overlap each other's launch gaps and tails)
@@ -232,7 +241,7 @@ def main():
     audio = torch.from_numpy(synth.make_audio(BATCH, SAMPLES, seed=100 + rank)).to(dev)
     alen = torch.full((BATCH,), SAMPLES, dtype=torch.int32, device=dev)
     T_out = eng.out_frames(engine.load_library().qasr_frontend_frames(SAMPLES, 16))
-    gathered = [torch.empty(BATCH, T_out, dtype=torch.int32, device=dev) for _ in range(world)] if rank == 0 else None
+    gathered = [torch.empty(BATCH, T_out, dtype=torch.int32, device=comm_dev) for _ in range(world)] if rank == 0 else None
 
     def step(i):
         k = i % S
@@ -246,7 +255,7 @@ def main():
             # step's compute stream; compute of later steps keeps running on the other streams
             torch.cuda.current_stream().wait_event(done)
             tokens.record_stream(torch.cuda.current_stream())
-            qdist.gather_tokens(tokens, 0, gathered)
+            qdist.gather_tokens(tokens if backend == 'nccl' else tokens.cpu(), 0, gathered)
         return tokens
 
     for i in range(max(args.warmup, S)):
@@ -267,7 +276,7 @@ def main():
     if not all(torch.equal(t_, last[0]) for t_ in last):
         raise SystemExit('bench: concurrent steps produced different tokens')
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
     audio_s = world * BATCH * SAMPLES / 16000.0 * args.steps
@@ -280,7 +289,7 @@ def main():
         'config': {'workload': 'QuartzNet15x5Base-En w8a8 percentile=99.996, bs=32/GPU, 5 s synthetic 16 kHz audio '
                                '(500 mel frames): HIP mel front-end + integer encoder + CTC decoder + greedy argmax',
                    'global_batch': BATCH * world, 'seq_len': FRAMES, 'weights': 'random-init (qasr.synth, seed 0)',
-                   'steps_in_flight': S, 'kernels': 'k_utt' if args.whole_utterance else 'k_sep', 'parallelism': f'utterance-sharded x{world}' + (', RCCL blob broadcast + token gather' if world > 1 else ''),
+                   'steps_in_flight': S, 'kernels': 'k_utt' if args.whole_utterance else 'k_sep', 'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + token gather' if world > 1 else ''),
                    'wer': 'not measurable here: no LibriSpeech / checkpoint in the image'},
     }
 
