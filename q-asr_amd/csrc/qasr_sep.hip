@@ -26,7 +26,8 @@ long long* g_prof = nullptr;
 #define SEP_NT 512          // threads per work-group (8 waves); 256 was measured slower at every concurrency level
 #endif
 #define SEP_PASS (SEP_NT / 2)  // output channels per GEMM pass (32 per wave)
-#define SEP_OP 48            // output staging row pitch (32 frames + 16)
+#define SEP_SP 36            // staging tile row pitch in words (32 frames + 4)
+#define SEP_STG_BYTES (SEP_NT / 64 * 32 * SEP_SP * 4)   // all waves' staging tiles
 
 // DIL == 2 (block 16, k = 87): out[t] = sum_k w[k] x[t - 86 + 2k] only touches frames of t's parity, so the window is
 // staged de-interleaved (one LDS row per channel and parity) and each parity stream sees an ordinary stride-1 conv with
@@ -114,11 +115,11 @@ __device__ __forceinline__ void sep_dump(int32_t* dbg, const v16i& a, int b, int
   }
 }
 
-// per-lane (= per output channel) epilogue parameters, fetched ahead of the GEMM that needs them
+// per-lane (= per output channel, MFMA C layout: channel = lane & 31) parameters, fetched ahead of the GEMM
 struct SepLaneP {
   int bias;
   float sb;
-  double m_main, m_out[QASR_MAX_OUTS];
+  double m_main;
 };
 template <int EP>
 __device__ __forceinline__ SepLaneP sep_lane_params(const SepP& p, int cor) {
@@ -127,10 +128,14 @@ __device__ __forceinline__ SepLaneP sep_lane_params(const SepP& p, int cor) {
   q.bias = p.bias[cor];
   q.sb = (EP == 0 || (e.flags & QASR_F_EXACT_Z)) ? e.sb[cor] : 1.0f;
   q.m_main = (EP == 2 || (EP == 0 && (e.flags & QASR_F_RESADD))) ? e.m_main[cor] : 0.0;
-#pragma unroll
-  for (int j = 0; j < QASR_MAX_OUTS; ++j)
-    q.m_out[j] = (EP != 2 && j < e.n_outs && e.outs[j].mode == 1) ? e.outs[j].mtab[cor] : 0.0;
   return q;
+}
+
+// wave-level LDS hand-over: DS operations of one wave execute in issue order, the fences only pin the compiler
+__device__ __forceinline__ void sep_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // EP selects the epilogue the kernel is specialised for (dead paths cost SGPRs, scalar reloads of the kernarg
@@ -158,7 +163,8 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
   int xr_bytes = 0;
   if (EP != EP_PLAIN)
     for (int k = 0; k < p.n_panes; ++k) xr_bytes = max(xr_bytes, SEP_TT * (p.panes[k].cin_pad + 16));
-  unsigned char* Ws = Xr + xr_bytes;                         // [256][WP]  depthwise window / output staging
+  unsigned char* Ws = Xr + xr_bytes;                         // [256][WP]  depthwise window, then the waves' staging tiles
+  int* const stg = (int*)Ws + wave * (32 * SEP_SP);          // this wave's [32 channels][32 frames] int32 tile
 
   // hot scalars are copied out of the (large, spilled) kernarg block once: re-reading them inside the unrolled
   // epilogue loops costs an s_load + wait per use
@@ -168,9 +174,9 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
   const int lim = (flags & QASR_F_MASK_OUT) ? min(len_b, eT) : eT;
   const int dlim = min(len_b, eT);                           // the 1x1 conv's MaskedConv1d masks its input
   const bool f_relu = flags & QASR_F_RELU;
-  const bool f_exact = flags & QASR_F_EXACT_Z;
   const bool f_resadd = GEN ? bool(flags & QASR_F_RESADD) : (EP == EP_RESADD1);
   const bool f_logits = GEN && (flags & QASR_F_LOGITS);
+  const bool f_exact = (flags & QASR_F_EXACT_Z) && !f_logits;   // logits are fl32(acc) * s_b, no QuantAct follows
   const int n_panes = GEN ? p.n_panes : (EP == EP_RESADD1 ? 1 : 0);
   const int dw_lo = p.dw_lo, dw_hi = p.dw_hi;
   const bool stamp = p.prof && blockIdx.x == 0 && blockIdx.y == 1 && tid == 0;
@@ -330,18 +336,6 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
     STAMP();
     if (DBG) sep_dump(e.acc_dbg, acc, b, co, ecout, t0, h, eT, eTp);
 
-    if (f_logits) {                                          // decoder: logits[b][t][co] = fl32(fl32(acc) * s_b[co])
-      if (co_ok) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int t = t0 + mfma32_row(r, h);
-          if (t < eT) e.logits[((size_t)b * eT + t) * ecout + co] = __fmul_rn((float)acc[r], cur.sb);
-        }
-      }
-      lp = nxt;
-      continue;
-    }
-
     int z[16];
     if (f_resadd) {
       // res_act (jasper.py:680-682; quant_utils.py:187-214): q = clamp(rq(out) + rq(res_i)), pane after pane
@@ -407,49 +401,70 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
     }
     STAMP();
 
+    // ---- hand the 32 x 32 int32 tile to the row layout through this wave's private LDS staging tile (no work-group
+    // barrier): lane (channel lane & 31) holds frames {8g + 4h .. +3}; afterwards lane l owns channel l >> 1, frames
+    // 16 (l & 1) .. +15, i.e. one 16-byte store per consumer.
+    {
+      int* wr = stg + (lane & 31) * SEP_SP + 4 * h;
 #pragma unroll
-    for (int j = 0; j < QASR_MAX_OUTS; ++j) {                // fully unrolled: cur.m_out[j] must stay in registers
+      for (int g = 0; g < 4; ++g) *(v4i*)(wr + 8 * g) = (v4i){z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]};
+    }
+    sep_wave_sync();
+    const int row = lane >> 1, half = lane & 1;
+    const int co2 = cbase + 32 * wave + row;                   // this lane's channel in the row layout
+    const bool co2_ok = co_in && co2 < ecout;
+    const int cor2 = co2_ok ? co2 : 0;
+    int zr[16];
+    {
+      const int* rd = stg + row * SEP_SP + 16 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const v4i v = *(const v4i*)(rd + 4 * g);
+        zr[4 * g] = v[0]; zr[4 * g + 1] = v[1]; zr[4 * g + 2] = v[2]; zr[4 * g + 3] = v[3];
+      }
+    }
+    sep_wave_sync();                                           // staging tile free for the next pass
+    const int tl0 = t0 + 16 * half;                            // first frame of this lane's 16
+    if (f_logits) {                                            // decoder: logits[b][t][co] = fl32(fl32(acc) * s_b[co])
+      if (co2_ok) {
+        const float sb2 = e.sb[cor2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (tl0 + i < eT) e.logits[((size_t)b * eT + tl0 + i) * ecout + co2] = __fmul_rn((float)zr[i], sb2);
+      }
+      lp = nxt;
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < QASR_MAX_OUTS; ++j) {
       if (j >= n_outs) break;
       const int omode = e.outs[j].mode, olo = e.outs[j].lo, ohi = e.outs[j].hi;
-      const double om = e.outs[j].m;
       void* const optr = e.outs[j].ptr;
       if (GEN && omode == 3) {                               // raw int32 (many-consumer values), rare path
-        if (co_ok) {
-          int* op = (int*)optr + ((size_t)b * ecout + co) * eTp + t0;
+        if (co2_ok) {
+          int* op = (int*)optr + ((size_t)b * ecout + co2) * eTp + tl0;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int tl = mfma32_row(r, h);
-            op[tl] = (t0 + tl < lim) ? z[r] : 0;
-          }
+          for (int i = 0; i < 16; ++i) op[i] = (tl0 + i < lim) ? zr[i] : 0;
         }
         continue;
       }
-      const double Mc = (EP == EP_PLAIN || omode == 1) ? cur.m_out[j] : om;
-      __syncthreads();                                       // Ws free (window consumed / previous out stored)
-      STAMP();
       int qo[16];
       if (EP != EP_PLAIN && omode == 2) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) qo[r] = z[r];
+        for (int i = 0; i < 16; ++i) qo[i] = zr[i];
       } else {
-        requant_batch<16>(qo, z, Mc, olo, ohi);
+        const double Mc = (EP == EP_PLAIN || omode == 1) ? e.outs[j].mtab[cor2] : e.outs[j].m;
+        requant_batch<16>(qo, zr, Mc, olo, ohi);
       }
+      v4i pk;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         int v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (t0 + mfma32_row(4 * g + i, h) < lim) ? qo[4 * g + i] : 0;
-        *(unsigned*)(Ws + co_l * SEP_OP + 8 * g + 4 * h) = pack4(v[0], v[1], v[2], v[3]);
+        for (int i = 0; i < 4; ++i) v[i] = (tl0 + 4 * g + i < lim) ? qo[4 * g + i] : 0;
+        pk[g] = (int)pack4(v[0], v[1], v[2], v[3]);
       }
-      STAMP();
-      __syncthreads();
-      STAMP();
-      {
-        const int row = tid >> 1, half = tid & 1;            // SEP_PASS rows x 2 halves of 16 B
-        const int cow = cbase + row;
-        if (cow < ecout)
-          *(v4i*)((int8_t*)optr + ((size_t)b * ecout + cow) * eTp + t0 + 16 * half) = *(const v4i*)(Ws + row * SEP_OP + 16 * half);
-      }
+      if (co2_ok) *(v4i*)((int8_t*)optr + ((size_t)b * ecout + co2) * eTp + tl0) = pk;
     }
     STAMP();
     lp = nxt;
@@ -461,7 +476,7 @@ static size_t sep_smem_bytes(const SepP& p, int WP) {
   size_t xs = (size_t)SEP_TT * (p.cin_pad + 16);
   size_t xr = 0;
   for (int k = 0; k < p.n_panes; ++k) xr = std::max(xr, (size_t)SEP_TT * (p.panes[k].cin_pad + 16));
-  size_t ws = std::max((size_t)256 * WP, (size_t)256 * SEP_OP);   // 256 LDS rows in either dilation mode
+  size_t ws = std::max((size_t)256 * WP, (size_t)SEP_STG_BYTES);  // 256 window rows in either dilation mode
   return xs + xr + ws;
 }
 
@@ -473,7 +488,7 @@ bool sep_supported(int K, int dilation) {
 template <int K, int DIL, int EP, bool DBG>
 static void launch_sep_v(hipStream_t s, const SepP& p) {
   using G = SepGeo<(K > 0 ? K : 1), DIL>;
-  const size_t smem = sep_smem_bytes(p, K > 0 ? G::WP : SEP_OP);
+  const size_t smem = sep_smem_bytes(p, K > 0 ? G::WP : 0);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_sep<K, DIL, EP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
