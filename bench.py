@@ -187,6 +187,9 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--tile', type=int, default=0, choices=[0, 32, 64],
+                    help='k_sep frames per work-group: 32 = lowest single-step latency, 64 = less weight/halo traffic '
+                         'per frame but half the work-groups; 0 = 64 when more than one step is in flight')
     ap.add_argument('--whole-utterance', action='store_true', help='use the k_utt kernels (one work-group per utterance)')
     ap.add_argument('--streams', type=int, default=int(os.environ.get('QASR_BENCH_STREAMS', 4)),
                     help='independent steps in flight per GPU (each on its own HIP stream + engine arena)')
@@ -233,7 +236,8 @@ def main():
     # throughput mode: consecutive steps are independent batches, so S of them are kept in flight, each on its own
     # HIP stream with its own engine arena (kernels of different steps overlap each other's launch gaps and tails)
     S = max(1, args.streams)
-    engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance) for _ in range(S)]
+    tile = args.tile or (64 if S > 1 else 32)
+    engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance, wide_tiles=(tile == 64)) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     eng = engs[0]
     log(f'{S} engine(s) ready ({len(blob) / 1e6:.1f} MB blob); warm-up')
@@ -268,6 +272,7 @@ def main():
     for i in range(args.steps):
         tokens = step(i)
         last = (last + [tokens])[-S:]
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -280,7 +285,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
     audio_s = world * BATCH * SAMPLES / 16000.0 * args.steps
-    log(f'timed {args.steps} steps: {1e3 * dt / args.steps:.3f} ms/step')
+    log(f'timed {args.steps} steps: {1e3 * dt / args.steps:.3f} ms/step (host enqueue {1e3 * t_enq / args.steps:.3f} ms/step)')
     result = {
         'metric': 'RTFx (audio-sec/wall-sec) QuartzNet15x5 int8 bs32', 'value': audio_s / dt, 'unit': 'audio-s/wall-s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
@@ -289,7 +294,7 @@ def main():
         'config': {'workload': 'QuartzNet15x5Base-En w8a8 percentile=99.996, bs=32/GPU, 5 s synthetic 16 kHz audio '
                                '(500 mel frames): HIP mel front-end + integer encoder + CTC decoder + greedy argmax',
                    'global_batch': BATCH * world, 'seq_len': FRAMES, 'weights': 'random-init (qasr.synth, seed 0)',
-                   'steps_in_flight': S, 'kernels': 'k_utt' if args.whole_utterance else 'k_sep', 'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + token gather' if world > 1 else ''),
+                   'steps_in_flight': S, 'kernels': 'k_utt' if args.whole_utterance else f'k_sep, {tile}-frame tiles', 'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + token gather' if world > 1 else ''),
                    'wer': 'not measurable here: no LibriSpeech / checkpoint in the image'},
     }
 

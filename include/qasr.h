@@ -129,7 +129,9 @@ typedef struct qasr_engine qasr_engine;
  * `debug` bit 0 keeps every intermediate tensor and int32 accumulator alive for qasr_engine_read_*;
  * bit 1 only records one HIP event per op on the launch stream (qasr_engine_last_op_ms), no other change;
  * bit 2 selects the whole-utterance kernels (k_utt: one work-group per utterance and layer, T <= 256 frames) instead of
- * the 32-frame tiles of k_sep - same results, meant for many steps in flight. */
+ * the 32-frame tiles of k_sep - same results, meant for many steps in flight;
+ * bit 3 makes k_sep use 64-frame tiles (half the weight / halo traffic per frame and half as many work-groups per
+ * launch: faster when several steps are in flight on separate streams, slower for a single step). */
 int qasr_engine_create(const void* blob, size_t blob_bytes, int device, int debug, qasr_engine** out);
 void qasr_engine_destroy(qasr_engine* e);
 

@@ -65,6 +65,7 @@ struct qasr_engine {
   bool legacy_pw = false;              // QASR_LEGACY_PW=1: stand-alone 1x1 convs through the v1 kernel k_pw
   std::vector<int> fused_dw;           // per op: index of the DW op fused into this PW op, or -1
   std::vector<char> skip;              // per op: launched as part of the following op
+  bool wide_tiles = false;             // k_sep with 64-frame tiles (throughput mode: bit 3 of `debug`, or QASR_WIDE_TILES=1)
   bool use_utt = true;                 // throughput mode: whole-utterance kernels (QASR_NO_UTT=1 disables)
   std::vector<char> utt;               // per op: 0 = k_sep, 1 = k_utt plain, 2 = k_utt residual pair (rq32 + add32)
   int32_t* r32 = nullptr;              // scratch [B][max cout][Tp] of the residual pair
@@ -309,6 +310,7 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
   e->legacy_pw = getenv("QASR_LEGACY_PW") != nullptr;
   // whole-utterance kernels (k_utt) are opt-in: bit 2 of `debug` or QASR_UTT=1 (throughput experiments)
   e->use_utt = (debug & 4) != 0 || getenv("QASR_UTT") != nullptr;
+  e->wide_tiles = (debug & 8) != 0 || getenv("QASR_WIDE_TILES") != nullptr;
   e->timing = (debug & 3) != 0;
   e->blob.assign((const uint8_t*)blob, (const uint8_t*)blob + n);
   e->h = h;
@@ -359,6 +361,7 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
   p.cin = (int)op.cin;
   p.cin_pad = rup(p.cin, 128);
   p.n_panes = (int)op.n_panes;
+  p.tile = e->wide_tiles ? 64 : 32;
   fill_panes(e, oi, op, p.panes);
   fill_epi(e, oi, op, p.e);
   const int di = e->fused_dw[oi];

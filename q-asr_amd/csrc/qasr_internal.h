@@ -77,7 +77,7 @@ struct SepP {             // fused separable layer: depthwise stencil -> QuantAc
   int32_t* dw_acc_dbg;    // optional i32 [B][cin][Tp]
   int dw_lo, dw_hi;       // clamp of that QuantAct
   int K, x_unsigned;      // taps (stride 1, 'same' padding)
-  int dilation, pad2_;    // 1, or 2 (window staged de-interleaved by parity)
+  int dilation, tile;     // dilation 1, or 2 (window staged de-interleaved by parity); tile: frames per work-group, 32 or 64
   // pointwise stage
   const int8_t* w;        // [cout_pad][cin_pad]
   const int32_t* bias;    // [cout_pad]

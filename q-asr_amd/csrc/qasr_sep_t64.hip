@@ -1,0 +1,6 @@
+// k_sep instantiations with 64-frame tiles (see qasr_sep_impl.h)
+#include "qasr_sep_impl.h"
+
+namespace qasr {
+template void launch_sep_inst<64, false>(hipStream_t, const SepP&);
+}  // namespace qasr

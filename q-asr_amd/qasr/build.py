@@ -7,7 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), 'csrc')
 LIB = os.path.join(HERE, 'libqasr_hip.so')
-SOURCES = ['qasr_kernels.hip', 'qasr_sep.hip', 'qasr_utt.hip', 'qasr_engine.hip', 'qasr_frontend.hip']
+SOURCES = ['qasr_kernels.hip', 'qasr_sep.hip', 'qasr_sep_t32.hip', 'qasr_sep_t32_dbg.hip', 'qasr_sep_t64.hip',
+           'qasr_sep_t64_dbg.hip', 'qasr_utt.hip', 'qasr_engine.hip', 'qasr_frontend.hip']
 
 
 def _stale():
@@ -24,11 +25,23 @@ def build_native(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    extra = os.environ.get('QASR_HIPCC_FLAGS', '').split()          # experiments: -DSEP_MIN_WAVES=4 ...
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB] + extra + srcs
-    if verbose:
-        print(' '.join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    extra = os.environ.get('QASR_HIPCC_FLAGS', '').split()          # experiments: -DSEP_WK=8 ...
+    # one object per translation unit, compiled in parallel (the k_sep instantiations dominate), then one link
+    objdir = os.path.join(os.path.dirname(HERE), 'build', 'obj')
+    os.makedirs(objdir, exist_ok=True)
+    objs = [os.path.join(objdir, os.path.basename(f)[:-4] + '.o') for f in srcs]
+
+    def compile_one(src, obj):
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-o', obj] + extra + [src]
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = max(1, min(len(srcs), (os.cpu_count() or 2)))
+    with ThreadPoolExecutor(jobs) as ex:
+        list(ex.map(lambda so: compile_one(*so), zip(srcs, objs)))
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB] + objs, check=True)
     return LIB
 
 

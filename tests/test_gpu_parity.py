@@ -112,12 +112,12 @@ def test_requant_exact_z_golden(eng, golden_dir):
 
 
 # ---------------------------------------------------------------------------------- networks
-def _run_engine(eng, golden_dir, name, debug=True, whole_utterance=False):
+def _run_engine(eng, golden_dir, name, debug=True, whole_utterance=False, wide_tiles=False):
     d, meta = _load(golden_dir, name)
     cfg = _cfg(name)
     sd = synth.make_state_dict(cfg, meta['seed'])
     blob, pm = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], meta['wbit'], meta['abit'])
-    e = eng.Engine(blob, 0, debug=debug, whole_utterance=whole_utterance)
+    e = eng.Engine(blob, 0, debug=debug, whole_utterance=whole_utterance, wide_tiles=wide_tiles)
     x = synth.make_features(meta['batch'], cfg.feat_in, meta['frames'], meta['seed'])
     logp, tokens, enc_len = e.forward(torch.from_numpy(x).cuda(), torch.tensor(meta['lengths']))
     torch.cuda.synchronize()
@@ -133,10 +133,14 @@ def _site_dims(cfg):
     return dims
 
 
-@pytest.mark.parametrize('whole_utterance', [False, True], ids=['k_sep', 'k_utt'])
+KERNEL_FAMILIES = [dict(), dict(wide_tiles=True), dict(whole_utterance=True)]
+KERNEL_IDS = ['k_sep32', 'k_sep64', 'k_utt']
+
+
+@pytest.mark.parametrize('family', KERNEL_FAMILIES, ids=KERNEL_IDS)
 @pytest.mark.parametrize('name', ['net_miniq_w8a8', 'net_miniq_w8a8_pct', 'net_miniq_w6a6', 'net_minij_w8a8'])
-def test_mini_net_every_accumulator(eng, golden_dir, name, whole_utterance):
-    d, meta, cfg, pm, e, logp, tokens, enc_len = _run_engine(eng, golden_dir, name, whole_utterance=whole_utterance)
+def test_mini_net_every_accumulator(eng, golden_dir, name, family):
+    d, meta, cfg, pm, e, logp, tokens, enc_len = _run_engine(eng, golden_dir, name, **family)
     couts = _site_dims(cfg)
     for i, (op, pane) in enumerate(pm['sites']):
         want = d[f'acc_{i}']                               # rint(conv_int) of the reference itself
@@ -148,10 +152,10 @@ def test_mini_net_every_accumulator(eng, golden_dir, name, whole_utterance):
     e.close()
 
 
-@pytest.mark.parametrize('whole_utterance', [False, True], ids=['k_sep', 'k_utt'])
+@pytest.mark.parametrize('family', KERNEL_FAMILIES, ids=KERNEL_IDS)
 @pytest.mark.parametrize('name', ['net_quartznet_w8a8', 'net_quartznet_w6a6', 'net_jasper_w8a8'])
-def test_full_net_checksums(eng, golden_dir, name, whole_utterance):
-    d, meta, cfg, pm, e, logp, tokens, enc_len = _run_engine(eng, golden_dir, name, whole_utterance=whole_utterance)
+def test_full_net_checksums(eng, golden_dir, name, family):
+    d, meta, cfg, pm, e, logp, tokens, enc_len = _run_engine(eng, golden_dir, name, **family)
     couts = _site_dims(cfg)
     T_out = d['tokens'].shape[1]
     for i, (op, pane) in enumerate(pm['sites']):
@@ -189,6 +193,10 @@ def test_bench_size_properties(eng, golden_dir):
     lpu, tku, _ = eu.forward(x, lens)                          # whole-utterance kernels: identical integers
     assert np.array_equal(tk1, tku.cpu().numpy()) and np.array_equal(lp1, lpu.cpu().numpy())
     eu.close()
+    ew = eng.Engine(blob, 0, debug=False, wide_tiles=True)     # 64-frame tiles: identical integers
+    lpw, tkw, _ = ew.forward(x, lens)
+    assert np.array_equal(tk1, tkw.cpu().numpy()) and np.array_equal(lp1, lpw.cpu().numpy())
+    ew.close()
     assert np.array_equal(el1, (lens.numpy() + 1) // 2)
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
     _, tk3, _ = e.forward(x[perm].contiguous(), lens[perm])
@@ -211,7 +219,7 @@ def test_steps_in_flight_match_serial(eng, golden_dir):
     sd = synth.make_state_dict(cfg, meta['seed'])
     blob, _ = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
     S = 4
-    engs = [eng.Engine(blob, 0) for _ in range(S)]
+    engs = [eng.Engine(blob, 0, wide_tiles=bool(k & 1)) for k in range(S)]   # both tile sizes in flight together
     streams = [torch.cuda.Stream() for _ in range(S)]
     B, T = 32, 512
     x = torch.from_numpy(synth.make_features(B, 64, T, 1)).cuda()
