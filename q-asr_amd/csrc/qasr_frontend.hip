@@ -1,7 +1,7 @@
 // Mel front-end on gfx950: AudioToMelSpectrogramPreprocessor / FilterbankFeatures.forward
 // (nemo/collections/asr/parts/features.py:334-397, normalize_batch :53-67), float32 throughout.
 //   k_mel   : one wavefront per STFT frame — pre-emphasis + reflect padding folded into the framing load,
-//             hann(320) window centred in 512, 512-point radix-2 FFT in LDS, power, 64x257 mel projection,
+//             hann(320) window centred in 512, 512-point real FFT (256-point complex radix-4 in LDS + even/odd split), power, 64x257 mel projection,
 //             log(x + 2^-24); writes un-normalised log-mel [B][n_mels][T_pad]
 //   k_norm  : one wavefront per (utterance, mel bin) row — mean / unbiased std over the valid frames,
 //             (x - mean) / (std + 1e-5), zero beyond seq_len and in the pad_to padding
@@ -16,7 +16,6 @@ namespace qasr {
 #define WIN 320
 #define WOFF 96      /* (512 - 320) / 2: torch.stft centres the window inside n_fft */
 
-__device__ __forceinline__ int bitrev9(int x) { return (int)(__brev((unsigned)x) >> 23); }
 
 // y[i] of the pre-emphasised, reflect-padded signal (features.py:347-348; torch.stft center=True, pad_mode='reflect')
 __device__ __forceinline__ float sample(const float* x, int S, int i, float preemph) {
@@ -57,67 +56,81 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#define MEL_FPW 2                          /* frames per wave per work-group (4 waves) */
+#define MEL_FPW 4                          /* frames per wave per work-group (4 waves) */
+
+__device__ __forceinline__ int rev4_256(int k) {          // reverse the four base-4 digits of k < 256
+  return ((k & 3) << 6) | ((k & 12) << 2) | ((k & 48) >> 2) | ((k & 192) >> 6);
+}
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// One wave per STFT frame.  The 512-point real FFT is computed as a 256-point complex FFT of z[n] = v[2n] + i v[2n+1]
+// (radix-4 decimation in frequency: 4 stages, one butterfly per lane and stage, results left in base-4 digit-reversed
+// order) followed by the usual even/odd split  X[k] = E[k] + e^{-2 pi i k/512} O[k],  k = 0..256.
 __global__ void __launch_bounds__(256) k_mel(const float* __restrict__ audio, int B, int S, const float* __restrict__ fb,
                                              const float* __restrict__ window, const int* __restrict__ ranges, int n_mels,
                                              float preemph, int n_frames, int T_pad, float* __restrict__ out) {
-  __shared__ float re[4][NFFT], im[4][NFFT];
-  __shared__ float twc[NFFT / 2], tws[NFFT / 2];
+  __shared__ float2 zb[4][NFFT / 2];       // per wave: complex work buffer
+  __shared__ float pw[4][NBIN + 3];        // per wave: power spectrum
+  __shared__ float2 tw[NFFT];              // e^{-2 pi i k / 512}, k < 512
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  {
-    float s, c;
-    sincospif(-2.0f * (float)tid / (float)NFFT, &s, &c);   // twiddles exp(-2*pi*i*k/512), k < 256
-    twc[tid] = c;
-    tws[tid] = s;
+  for (int k = tid; k < NFFT; k += 256) {
+    float sn, cs;
+    sincospif(-2.0f * (float)k / (float)NFFT, &sn, &cs);
+    tw[k] = make_float2(cs, sn);
   }
   __syncthreads();
-  float* wre = re[wave];
-  float* wim = im[wave];
+  float2* z = zb[wave];
+  float* P = pw[wave];
   for (int it = 0; it < MEL_FPW; ++it) {
     const int fidx = (blockIdx.x * MEL_FPW + it) * 4 + wave;   // frame index over B * n_frames
     const bool ok = fidx < B * n_frames;
     const int b = ok ? fidx / n_frames : 0, t = ok ? fidx - b * n_frames : 0;
     const float* x = audio + (size_t)b * S;
     wave_sync_lds();                       // previous frame's spectrum consumed
-    // framing: sample j of frame t is ypad[160 t + j], ypad index 0 <-> signal index -256
+    // framing: sample j of frame t is ypad[160 t + j], ypad index 0 <-> signal index -256; z[n] = v[2n] + i v[2n+1]
 #pragma unroll
-    for (int i = 0; i < NFFT / 64; ++i) {
-      const int j = lane + 64 * i;
-      float v = 0.f;
-      if (j >= WOFF && j < WOFF + WIN) v = __fmul_rn(sample(x, S, HOP * t + j - NFFT / 2, preemph), window[j - WOFF]);
-      const int r = bitrev9(j);
-      wre[r] = v;
-      wim[r] = 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const int n = lane + 64 * i, j = 2 * n;
+      float2 v = make_float2(0.f, 0.f);
+      if (j >= WOFF && j < WOFF + WIN) {
+        v.x = __fmul_rn(sample(x, S, HOP * t + j - NFFT / 2, preemph), window[j - WOFF]);
+        v.y = __fmul_rn(sample(x, S, HOP * t + j + 1 - NFFT / 2, preemph), window[j + 1 - WOFF]);
+      }
+      z[n] = v;
     }
     wave_sync_lds();
-    // in-place radix-2 DIT, 9 stages, 4 butterflies per lane per stage
-#pragma unroll 1
-    for (int s = 1; s <= 9; ++s) {
-      const int half = 1 << (s - 1), m = half << 1, tstep = NFFT / m;
+    // radix-4 DIF: spans 256, 64, 16, 4; lane = butterfly
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = lane + 64 * q;
-        const int pos = i & (half - 1), grp = i >> (s - 1);
-        const int a = grp * m + pos, bb = a + half;
-        const float wr = twc[pos * tstep], wi = tws[pos * tstep];
-        const float xr = wre[bb], xi = wim[bb];
-        const float tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
-        const float ar = wre[a], ai = wim[a];
-        wre[a] = ar + tr;
-        wim[a] = ai + ti;
-        wre[bb] = ar - tr;
-        wim[bb] = ai - ti;
-      }
+    for (int st = 0; st < 4; ++st) {
+      const int L = 256 >> (2 * st), q4 = L >> 2;            // block length, quarter
+      const int blk = lane / q4, j = lane - blk * q4;
+      const int base = blk * L + j;
+      const float2 a0 = z[base], a1 = z[base + q4], a2 = z[base + 2 * q4], a3 = z[base + 3 * q4];
+      const float2 s02 = make_float2(a0.x + a2.x, a0.y + a2.y), d02 = make_float2(a0.x - a2.x, a0.y - a2.y);
+      const float2 s13 = make_float2(a1.x + a3.x, a1.y + a3.y), d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
+      // -i * d13 = (d13.y, -d13.x)
+      const float2 b0 = make_float2(s02.x + s13.x, s02.y + s13.y);
+      const float2 b2 = make_float2(s02.x - s13.x, s02.y - s13.y);
+      const float2 b1 = make_float2(d02.x + d13.y, d02.y - d13.x);
+      const float2 b3 = make_float2(d02.x - d13.y, d02.y + d13.x);
+      const int ts = (NFFT / L) * j;                          // W_L^j = tw[(512 / L) j]
+      z[base] = b0;
+      z[base + q4] = cmul(b1, tw[ts]);
+      z[base + 2 * q4] = cmul(b2, tw[2 * ts]);
+      z[base + 3 * q4] = cmul(b3, tw[3 * ts]);
       wave_sync_lds();
     }
-    // power spectrum: the reference takes sqrt(re^2+im^2) and then pow(2) (features.py:356-360)
+    // even/odd split and power spectrum: the reference takes sqrt(re^2+im^2) and then pow(2) (features.py:356-360)
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int k = lane + 64 * i;
-      if (k < NBIN) {
-        const float r = wre[k], q = wim[k];
-        const float mag = sqrtf(r * r + q * q);
-        wre[k] = mag * mag;
+      if (k <= NFFT / 2) {
+        const float2 zk = z[rev4_256(k & 255)], zc = z[rev4_256((256 - k) & 255)];
+        const float2 E = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+        const float2 O = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));   // -i (zk - conj(zc)) / 2
+        const float2 X = make_float2(E.x + O.x * tw[k].x - O.y * tw[k].y, E.y + O.x * tw[k].y + O.y * tw[k].x);
+        const float mag = sqrtf(X.x * X.x + X.y * X.y);
+        P[k] = mag * mag;
       }
     }
     wave_sync_lds();
@@ -128,7 +141,7 @@ __global__ void __launch_bounds__(256) k_mel(const float* __restrict__ audio, in
         const float* f = fb + (size_t)m * NBIN;
         const int lo = ranges[2 * m], hi = ranges[2 * m + 1];
         float acc = 0.f;
-        for (int k = lo; k < hi; ++k) acc = fmaf(f[k], wre[k], acc);
+        for (int k = lo; k < hi; ++k) acc = fmaf(f[k], P[k], acc);
         out[((size_t)b * n_mels + m) * T_pad + t] = logf(acc + 5.9604644775390625e-08f);   // 2^-24
       }
     }
