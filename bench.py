@@ -305,8 +305,16 @@ def main():
         ms = eng.time_ops(reps=20).astype(np.float64)
         result['roofline'] = dominant_kernel_roofline(eng, cfg, meta, ms, BATCH, FRAMES // 2)
         mfma_ops, dw_ops, _ = algorithmic_work(cfg, BATCH, FRAMES // 2)
+        # whole-step view (all launches, steps in flight as timed): SURVEY §8d bytes = every conv reads its int8 input
+        # once, writes its output once, weights once (1065.9 + 18.85 MB at B=32, T'=250)
+        step_bytes = 1065.9e6 * BATCH / 32 + 18.85e6
         result['roofline']['other'].update(step_mfma_class_gop=mfma_ops / 1e9, step_depthwise_gop=dw_ops / 1e9,
-                                           step_mfma_class_top_s=mfma_ops / (dt / args.steps) / 1e12)
+                                           step_mfma_class_top_s=mfma_ops / (dt / args.steps) / 1e12,
+                                           step_algorithmic_gb_s=step_bytes / (dt / args.steps) / 1e9,
+                                           step_hbm_frac=step_bytes / (dt / args.steps) / PEAK_HBM,
+                                           work_groups_per_launch=BATCH * 256 // tile,
+                                           note='a 64-frame-tile launch fills 128 of the 256 CUs; the bench keeps two '
+                                                'such launches (of different steps) on the chip at a time')
 
         # ---- CPU baseline: the reference's fake-quant op sequence on this host's cores (N=1 only) --------------
         if world == 1 and not args.no_cpu_baseline:
