@@ -163,6 +163,18 @@ int qasr_engine_op_label(qasr_engine* e, int op, char* buf, size_t cap);
 /* Re-enqueue a single op of the last forward's plan (diagnostics / profiling of one layer). */
 int qasr_engine_run_op(qasr_engine* e, void* stream, int op);
 
+/* ---- calibration helper -------------------------------------------------------- */
+
+/* The two torch.quantile calls of QuantAct's percentile calibration
+ * (nemo/quantization/utils/quant_modules.py:121-125: x_min = quantile(x_act, 1 - p/100), x_max = quantile(x_act, p/100))
+ * over a flattened float32 device tensor of n elements (16-byte aligned, finite values): exact order statistics by a
+ * 4-pass radix select + torch's float32 linear interpolation.  out2[0] = quantile(q_lo), out2[1] = quantile(q_hi);
+ * bit-identical to torch.quantile on the CPU.  Enqueued on `stream`; `workspace` (device, qasr_quantile_workspace_bytes()
+ * bytes) must stay untouched until the stream has finished. */
+size_t qasr_quantile_workspace_bytes(void);
+int qasr_quantile2(void* stream, const float* x, size_t n, float q_lo, float q_hi, float* out2, void* workspace,
+                   size_t workspace_bytes);
+
 /* ---- stand-alone operators (same kernels the engine launches; device pointers) -------------- */
 
 /* AudioToMelSpectrogramPreprocessor.forward / FilterbankFeatures.forward

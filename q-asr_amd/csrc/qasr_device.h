@@ -75,8 +75,16 @@ __device__ __forceinline__ double requant_d(int z, double M) { return rint((doub
 
 // z_int = round(x / pre_act_scaling_factor) of fixedpoint_mul (quant_utils.py:187) taken through the
 // float32 view y = fl32(fl32(acc) * s_b); equals acc whenever |acc| < 2^22 (then the caller skips this).
+// a * b rounded to float32 as an operation of its own: HIP's __fmul_rn is a plain operator that the backend contracts
+// with a following add/sub into v_fma_f32 (pragmas notwithstanding), so the product is made opaque
+__device__ __forceinline__ float mul_f32_unfused(float a, float b) {
+  float r;
+  asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ int z_roundtrip(int acc, float sb, bool relu) {
-  float y = __fmul_rn((float)acc, sb);
+  float y = mul_f32_unfused((float)acc, sb);
   if (relu) y = fmaxf(y, 0.0f);
   return (int)rintf(__fdiv_rn(y, sb));
 }

@@ -6,7 +6,7 @@
 //   k_norm  : one wavefront per (utterance, mel bin) row — mean / unbiased std over the valid frames,
 //             (x - mean) / (std + 1e-5), zero beyond seq_len and in the pad_to padding
 // Float parity with the reference is tolerance based (FFT / reduction order): tests/test_gpu_frontend.py.
-#include "qasr_internal.h"
+#include "qasr_device.h"
 
 namespace qasr {
 
@@ -22,7 +22,7 @@ __device__ __forceinline__ float sample(const float* x, int S, int i, float pree
   int ii = i < 0 ? -i : (i >= S ? 2 * (S - 1) - i : i);
   ii = min(max(ii, 0), S - 1);
   float v = x[ii];
-  if (ii > 0) v = v - __fmul_rn(preemph, x[ii - 1]);
+  if (ii > 0) v = v - mul_f32_unfused(preemph, x[ii - 1]);   // two float32 steps, like features.py:347-348
   return v;
 }
 

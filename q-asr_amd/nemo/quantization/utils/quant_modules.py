@@ -62,6 +62,11 @@ class QuantAct(Module):
                 return x.amin(dim=(0, 2)), x.amax(dim=(0, 2))
             return x.min(), x.max()
         assert not self.per_channel, 'percentile mode is only available for the global quantization mode'
+        if x.is_cuda and x.numel() > 1:
+            # both quantiles in one radix select on device (csrc/qasr_calib.hip), bit-identical to torch.quantile on CPU
+            from qasr import engine
+            r = engine.quantile2(x.float(), 1 - self.percentile / 100, self.percentile / 100)
+            return r[0], r[1]
         return (_quantile(x, torch.tensor(1 - self.percentile / 100, device=x.device)),
                 _quantile(x, torch.tensor(self.percentile / 100, device=x.device)))
 

@@ -13,7 +13,8 @@ SYMBOLS = ['qasr_engine_create', 'qasr_engine_destroy', 'qasr_engine_forward', '
            'qasr_engine_num_ops', 'qasr_engine_read_acc', 'qasr_engine_read_tensor', 'qasr_engine_last_op_ms',
            'qasr_engine_time_ops', 'qasr_engine_run_op', 'qasr_engine_op_label',
            'qasr_frontend_mel', 'qasr_frontend_frames', 'qasr_frontend_workspace_bytes', 'qasr_pw_conv_acc',
-           'qasr_dw_conv_acc', 'qasr_requant', 'qasr_debug_prof', 'qasr_last_error', 'qasr_version']
+           'qasr_dw_conv_acc', 'qasr_requant', 'qasr_quantile2', 'qasr_quantile_workspace_bytes', 'qasr_debug_prof',
+           'qasr_last_error', 'qasr_version']
 
 _lib = None
 
@@ -52,6 +53,9 @@ def load_library():
     lib.qasr_dw_conv_acc.argtypes = [vp, vp, i32, vp] + [i32] * 11 + [vp]
     lib.qasr_requant.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.qasr_debug_prof.argtypes = [vp]
+    lib.qasr_quantile2.argtypes = [vp, vp, sz, C.c_float, C.c_float, vp, vp, sz]
+    lib.qasr_quantile_workspace_bytes.argtypes = []
+    lib.qasr_quantile_workspace_bytes.restype = sz
     lib.qasr_last_error.restype = C.c_char_p
     lib.qasr_version.restype = C.c_char_p
     _lib = lib
@@ -248,3 +252,16 @@ def frontend_mel(audio: torch.Tensor, lens: torch.Tensor, fb: torch.Tensor, wind
                                  C.c_float(preemph), pad_to, _ptr(feats), _ptr(flens), _ptr(ws), ws.numel()),
            'qasr_frontend_mel')
     return feats, flens
+
+
+def quantile2(x: torch.Tensor, q_lo: float, q_hi: float):
+    """qasr_quantile2: (torch.quantile(x.flatten(), q_lo), torch.quantile(x.flatten(), q_hi)) of a float32 cuda tensor
+    as one radix select on device; returns a 2-element float32 cuda tensor (no host synchronisation)."""
+    lib = load_library()
+    assert x.is_cuda and x.dtype == torch.float32
+    flat = x.detach().contiguous().view(-1)
+    out = torch.empty(2, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.qasr_quantile_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    _check(lib.qasr_quantile2(_stream_ptr(), _ptr(flat), flat.numel(), C.c_float(q_lo), C.c_float(q_hi), _ptr(out), _ptr(ws),
+                              ws.numel()), 'qasr_quantile2')
+    return out

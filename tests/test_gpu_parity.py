@@ -238,3 +238,30 @@ def test_steps_in_flight_match_serial(eng, golden_dir):
         assert np.array_equal(lp.cpu().numpy(), lp0), f'step {i} (engine {i % S}) log-probs differ from the serial run'
     for e in engs:
         e.close()
+
+
+def test_device_quantile_matches_torch_cpu(eng):
+    """qasr_quantile2 (radix select on device) against torch.quantile on the CPU and the oracle restatement: bit-exact,
+    including ties, negative values, tiny inputs and the bench-size activation tensor (32 x 1024 x 256)."""
+    from oracle import int_oracle as O
+    g = torch.Generator().manual_seed(3)
+    cases = [torch.randn(100003, generator=g), torch.randn(32, 256, 250, generator=g) * 7, torch.randn(4, generator=g),
+             torch.tensor([3.0, -1.0]), torch.full((1000,), 2.5), torch.round(torch.randn(50000, generator=g) * 4),
+             torch.relu(torch.randn(32, 1024, 256, generator=g))]
+    for x in cases:
+        for p in (99.996, 99.9, 100.0, 50.0):
+            ql, qh = 1 - p / 100, p / 100
+            got = eng.quantile2(x.cuda(), ql, qh).cpu().numpy()
+            flat = x.reshape(-1)
+            want = [torch.quantile(flat, torch.tensor(q, dtype=torch.float32)).item() if flat.numel() <= 16_000_000
+                    else float(O.quantile_f32(flat.numpy(), np.float32(q))) for q in (ql, qh)]
+            assert got[0] == np.float32(want[0]) and got[1] == np.float32(want[1]), (tuple(x.shape), p, got, want)
+            if flat.numel() <= 200000:
+                assert got[0] == O.quantile_f32(flat.numpy(), np.float32(ql))
+    rng = np.random.default_rng(5)                          # two-element inputs: w = q, separates fused from unfused lerp
+    for _ in range(200):
+        a = np.float32(rng.standard_normal() * 10)
+        x = np.array([a, np.float32(a + abs(rng.standard_normal()) * 0.1), 0, 0], np.float32)[:2]
+        q = float(np.float32(rng.random()))
+        got = eng.quantile2(torch.from_numpy(x.copy()).cuda(), q, q).cpu().numpy()
+        assert got[0] == O.quantile_f32(x, np.float32(q)) and got[1] == got[0], (x, q, got)

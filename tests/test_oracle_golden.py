@@ -173,3 +173,24 @@ def test_cpu_baseline_port_matches_reference(golden_dir, name):
             assert np.array_equal(yi.astype(np.int32), d[f'acc_{i}']), i
         else:
             assert np.array_equal(O.checksum(yi), d['conv_checksums'][i][:2]), i
+
+
+def test_quantile_restatement_matches_torch():
+    """oracle.quantile_f32 restates torch.quantile (what QuantAct's percentile calibration calls) bit for bit."""
+    import torch
+    rng = np.random.default_rng(7)
+    cases = [rng.standard_normal(100003).astype(np.float32), rng.standard_normal(4096).astype(np.float32) * 50,
+             np.abs(rng.standard_normal(65536)).astype(np.float32), np.array([3.0, -1.0], np.float32),
+             np.full(1000, 2.5, np.float32), np.round(rng.standard_normal(50000) * 4).astype(np.float32)]
+    for x in cases:
+        for q in (1 - 99.996 / 100, 99.996 / 100, 0.0, 1.0, 0.5, 0.001, 0.9999):
+            want = torch.quantile(torch.from_numpy(x), torch.tensor(q, dtype=torch.float32)).numpy()
+            got = O.quantile_f32(x, np.float32(q))
+            assert got == want, (x.size, q, got, want)
+    # two-element inputs make w = q: many of these separate a fused lerp from an unfused one
+    for _ in range(3000):
+        a = np.float32(rng.standard_normal() * 10)
+        x = np.array([a, np.float32(a + abs(rng.standard_normal()) * 0.1)], np.float32)
+        q = np.float32(rng.random())
+        want = torch.quantile(torch.from_numpy(x), torch.tensor(q)).numpy()
+        assert O.quantile_f32(x, q) == want, (x, q)
