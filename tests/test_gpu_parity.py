@@ -265,3 +265,30 @@ def test_device_quantile_matches_torch_cpu(eng):
         q = float(np.float32(rng.random()))
         got = eng.quantile2(torch.from_numpy(x.copy()).cuda(), q, q).cpu().numpy()
         assert got[0] == O.quantile_f32(x, np.float32(q)) and got[1] == got[0], (x, q, got)
+
+
+@pytest.mark.parametrize('family', KERNEL_FAMILIES, ids=KERNEL_IDS)
+def test_odd_sizes_against_oracle(eng, golden_dir, family):
+    """Edge shapes the reference's MaskedConv1d handles (jasper.py:170-183): a single short utterance, lengths of
+    1 frame, lengths that are not multiples of any tile, T beyond one 256-frame window, every utterance shorter
+    than the padded batch.  Tokens and integer log-prob inputs must equal the oracle on the valid frames."""
+    from oracle import int_oracle as O
+    d, meta = _load(golden_dir, 'net_miniq_w8a8')
+    cfg = _cfg('net_miniq_w8a8')
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    blob, pm = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    net = O.OracleNet(topology.conv_plan(cfg), cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    e = eng.Engine(blob, 0, **family)
+    cases = [(1, 16, [16]), (1, 33, [33]), (3, 40, [1, 17, 40]), (2, 70, [2, 69]), (2, 600, [600, 301]),
+             (5, 130, [129, 64, 65, 1, 128]), (4, 96, [50, 50, 50, 50])]
+    for B, T, lens in cases:
+        x = synth.make_features(B, cfg.feat_in, T, 100 + T)
+        want = net.forward(x, lens)
+        logp, tok, elen = e.forward(torch.from_numpy(x).cuda(), torch.tensor(lens))
+        tok, elen, logp = tok.cpu().numpy(), elen.cpu().numpy(), logp.cpu().numpy()
+        assert np.array_equal(elen, want['enc_len']), (B, T, lens)
+        for b in range(B):
+            n = int(want['enc_len'][b])
+            assert np.array_equal(tok[b, :n], want['tokens'][b, :n]), (B, T, lens, b)
+            np.testing.assert_allclose(logp[b, :n], want['log_probs'][b, :n], rtol=1e-4, atol=5e-5)
+    e.close()
