@@ -384,6 +384,15 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
     p.K = 0;
     p.dilation = 1;
     p.pw_unsigned = tin.d.dtype == QASR_DT_U8;
+    if (op.kind == QASR_OP_DENSE) {
+      p.dense_k = (int)op.kernel;
+      p.dilation = (int)op.dilation;
+      // the window of all input channels must fit the LDS next to the residual operand and the staging tiles
+      const int halo = ((p.dense_k - 1) * p.dilation / 2 + 3) & ~3;
+      size_t xr = 0;
+      for (int k = 0; k < p.n_panes; ++k) xr = std::max(xr, (size_t)64 * (p.panes[k].cin_pad + 16));
+      if ((size_t)(64 + 2 * halo) * (p.cin_pad + 16) + xr + 37 * 1024 > 160 * 1024) p.tile = 32;
+    }
   }
 }
 
@@ -476,6 +485,12 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
       break;
     }
     case QASR_OP_DENSE: {
+      if (op.flags & QASR_F_TAPMAJOR) {                     // stride-1 'same' dense conv: taps shifted 1x1 GEMMs on the tile kernel
+        SepP p{};
+        build_sep(e, oi, p);
+        launch_sep(s, p);
+        break;
+      }
       DenseP p{};
       p.x = (const int8_t*)tin.ptr;
       p.w = dev_at<int8_t>(e, op.w_off);
@@ -582,7 +597,15 @@ int qasr_engine_op_label(qasr_engine* e, int op, char* buf, size_t cap) {
   else switch (d.kind) {
     case QASR_OP_QUANT_IN: name = "k_quant_in"; break;
     case QASR_OP_DW: name = "k_dw"; break;
-    case QASR_OP_DENSE: name = "k_dense"; break;
+    case QASR_OP_DENSE:
+      if (d.flags & QASR_F_TAPMAJOR) {
+        SepP p{};
+        build_sep(e, (uint32_t)op, p);
+        sep_kernel_label(p, buf, cap);
+        return QASR_OK;
+      }
+      name = "k_dense";
+      break;
     case QASR_OP_LOGSOFTMAX: name = "k_logsoftmax"; break;
     case QASR_OP_REQUANT: name = "k_requant"; break;
     case QASR_OP_PW:

@@ -82,6 +82,7 @@ struct SepP {             // fused separable layer: depthwise stencil -> QuantAc
   const int8_t* w;        // [cout_pad][cin_pad]
   const int32_t* bias;    // [cout_pad]
   int cin, cin_pad, pw_unsigned, n_panes;
+  int dense_k, pad3_;     // > 1: dense conv with that many taps (K == 0 kernels; `w` tap-major, `dilation` = tap spacing)
   const int32_t* r32;     // k_utt EP_ADD32: res_act operand rint(acc_res * M_res) of the block's residual conv
   long long* prof;        // diagnostics: s_memtime stamps of work-group (0,0,0), wave 0 (qasr_debug_prof)
   PaneP panes[QASR_MAX_PANES];

@@ -51,17 +51,20 @@ struct SepGeo {
 };
 
 // ---- stage an input tile [cin][32] into LDS transposed as Xs[frame][channel] (4x4 byte transposes) ------------
-template <int TT>
-__device__ __forceinline__ void sep_stage_transposed(unsigned char* Xs, int XP, const int8_t* __restrict__ x, int cin,
-                                                     int cin_pad, int Tp, int b, int t0, bool x_unsigned) {
+// `rows` frames starting at frame tf (both multiples of 4); frames outside [0, Tp) read as 0 (conv zero padding)
+__device__ __forceinline__ void sep_stage_rows(unsigned char* Xs, int XP, const int8_t* __restrict__ x, int cin, int cin_pad,
+                                               int Tp, int b, int tf, int rows, bool x_unsigned) {
   const unsigned flip = x_unsigned ? 0x80808080u : 0u;
-  for (int task = threadIdx.x; task < (cin_pad / 4) * (TT / 4); task += SEP_NT) {
-    const int cq = task / (TT / 4), tq = task % (TT / 4);   // 4 channels x 4 frames
+  const int rq = rows >> 2;
+  for (int task = threadIdx.x; task < (cin_pad / 4) * rq; task += SEP_NT) {
+    const int cq = task / rq, tq = task - cq * rq;          // 4 channels x 4 frames
+    const int t = tf + 4 * tq;
+    const bool t_ok = t >= 0 && t < Tp;
     unsigned r[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ci = 4 * cq + j;
-      r[j] = (ci < cin) ? *(const unsigned*)(x + ((size_t)b * cin + ci) * Tp + t0 + 4 * tq) : 0u;
+      r[j] = (ci < cin && t_ok) ? *(const unsigned*)(x + ((size_t)b * cin + ci) * Tp + t) : 0u;
     }
     const unsigned lo01 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u), hi01 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);
     const unsigned lo23 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u), hi23 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
@@ -71,6 +74,11 @@ __device__ __forceinline__ void sep_stage_transposed(unsigned char* Xs, int XP, 
     *(unsigned*)(dst + 2 * XP) = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u) ^ flip;
     *(unsigned*)(dst + 3 * XP) = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u) ^ flip;
   }
+}
+template <int TT>
+__device__ __forceinline__ void sep_stage_transposed(unsigned char* Xs, int XP, const int8_t* __restrict__ x, int cin,
+                                                     int cin_pad, int Tp, int b, int t0, bool x_unsigned) {
+  sep_stage_rows(Xs, XP, x, cin, cin_pad, Tp, b, t0, TT, x_unsigned);
 }
 
 // ---- weight fragments of one wave: W[co_row][kc + 32*ks + 16*h .. +15], ks < SEP_WK (one 512-deep K slab) ------
@@ -114,6 +122,62 @@ __device__ __forceinline__ void sep_gemm(v16i (&acc)[MT], v4i (&wf)[SEP_WK], con
   for (int kc = 0; kc < cin_pad; kc += 32 * SEP_WK) {
     if (kc) sep_load_w(wf, w, cin_pad, co_row, kc);
     sep_mfma_chunk(acc, wf, Xs, XP, cin_pad, kc);
+  }
+}
+
+// Dense k > 1 conv (Jasper, jasper.py:601-630) on the same tile: out[t] = sum_k W_k x[t + k*dil - pad] is a sum of taps 1x1
+// GEMMs whose A rows are the staged window shifted by k*dil frames.  Weights are tap-major (pack.py: one fragment-
+// ordered [cout_pad][cin_pad] matrix per tap).  Work items = (tap, 256-deep half slab); two register buffers so that
+// the fragments of item i+1 travel while item i is on the matrix cores.
+#define SEP_DK 8                                             /* K steps (of 32) per item */
+__device__ __forceinline__ void sep_load_wd(v4i (&wf)[SEP_DK], const int8_t* __restrict__ w, int cin_pad, int co_row, int kc) {
+  const v4i* wp = w_frag(w, cin_pad, co_row, kc >> 5);
+#pragma unroll
+  for (int g = 0; g < SEP_DK / 4; ++g)
+    if (kc + 128 * g < cin_pad) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[4 * g + i] = wp[64 * (4 * g + i)];
+    }
+}
+template <int MT>
+__device__ __forceinline__ void sep_mfma_d(v16i (&acc)[MT], const v4i (&wf)[SEP_DK], const unsigned char* Xrow, int XP, int cin_pad,
+                                           int kc) {
+  const int lane = threadIdx.x & 63, h = lane >> 5, r31 = lane & 31;
+  const unsigned char* arow = Xrow + r31 * XP + kc + 16 * h;
+#pragma unroll
+  for (int g = 0; g < SEP_DK / 4; ++g)
+    if (kc + 128 * g < cin_pad) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        v4i a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *(const v4i*)(arow + 32 * mt * XP + 32 * (4 * g + i));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], wf[4 * g + i], acc[mt], 0, 0, 0);
+      }
+    }
+}
+template <int MT>
+__device__ __forceinline__ void sep_gemm_taps(v16i (&acc)[MT], const unsigned char* Xs0, int XP, const int8_t* __restrict__ w,
+                                              int cin_pad, int cout_pad, int co_row, int taps, int dil) {
+  const int nh = (cin_pad + 32 * SEP_DK - 1) / (32 * SEP_DK);       // half slabs per tap
+  const int total = taps * nh;
+  const size_t tap_bytes = (size_t)cout_pad * cin_pad;
+  v4i wa[SEP_DK], wb[SEP_DK];
+  auto load = [&](v4i (&wf)[SEP_DK], int i) {
+    const int tap = i / nh, hs = i - tap * nh;
+    sep_load_wd(wf, w + tap * tap_bytes, cin_pad, co_row, 32 * SEP_DK * hs);
+  };
+  auto mma = [&](const v4i (&wf)[SEP_DK], int i) {
+    const int tap = i / nh, hs = i - tap * nh;
+    sep_mfma_d<MT>(acc, wf, Xs0 + tap * dil * XP, XP, cin_pad, 32 * SEP_DK * hs);
+  };
+  load(wa, 0);
+  for (int i = 0; i < total; i += 2) {
+    if (i + 1 < total) load(wb, i + 1);
+    mma(wa, i);
+    if (i + 2 < total) load(wa, i + 2);
+    if (i + 1 < total) mma(wb, i + 1);
   }
 }
 
@@ -171,8 +235,11 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
   // produced them run on XCD b % 8 and find their halos / inputs in that XCD's L2.
   const int b = blockIdx.x, t0 = blockIdx.y * TT;
   const int XP = p.cin_pad + 16;
-  unsigned char* Xs = smem;                                  // [32][XP]   A operand of the main GEMM
-  unsigned char* Xr = Xs + TT * XP;                      // [32][XPr]  A operand of the residual GEMMs
+  // dense k > 1 conv (K == 0 instantiations only): taps, 'same' padding (taps-1)*dil/2, window halo rounded up to 4 frames
+  const bool dense = K == 0 && p.dense_k > 1;
+  const int dpad = dense ? (p.dense_k - 1) * p.dilation / 2 : 0, dhalo = (dpad + 3) & ~3;
+  unsigned char* Xs = smem;                                  // [TT (+ 2 dhalo)][XP]   A operand of the main GEMM
+  unsigned char* Xr = Xs + (TT + 2 * dhalo) * XP;            // [TT][XPr]  A operand of the residual GEMMs
   int xr_bytes = 0;
   if (EP != EP_PLAIN)
     for (int k = 0; k < p.n_panes; ++k) xr_bytes = max(xr_bytes, TT * (p.panes[k].cin_pad + 16));
@@ -204,7 +271,7 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
   const bool in0 = co_l < cout_pad;
   SepLaneP lp = sep_lane_params<EP>(p, in0 ? co_l : 0);
   v4i wf[SEP_WK];
-  sep_load_w(wf, p.w, p.cin_pad, in0 ? co_l : 0, 0);        // consumed after the depthwise stage, which hides it
+  if (!dense) sep_load_w(wf, p.w, p.cin_pad, in0 ? co_l : 0, 0);        // consumed after the depthwise stage, which hides it
   __builtin_amdgcn_sched_barrier(0);                         // keep the requests up here (the scheduler sinks them to first use)
 
   if (K > 0) {
@@ -316,6 +383,9 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
       const int r = i / (p.cin_pad - p.cin), cc = i - r * (p.cin_pad - p.cin);
       Xs[r * XP + p.cin + cc] = 0;
     }
+  } else if (dense) {
+    // dense conv: window of TT + 2*dhalo frames, every input channel; A rows of tap k start at row dhalo - pad + k*dil
+    sep_stage_rows(Xs, XP, p.x, p.cin, p.cin_pad, e.Tp, b, t0 - dhalo, TT + 2 * dhalo, p.pw_unsigned);
   } else {
     sep_stage_transposed<TT>(Xs, XP, p.x, p.cin, p.cin_pad, e.Tp, b, t0, p.pw_unsigned);
   }
@@ -338,7 +408,10 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
     for (int mt = 0; mt < SEP_MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][r] = cur.bias;
-    if (co_in) sep_gemm(acc, wf, Xs, XP, p.w, p.cin_pad, cor);
+    if (co_in) {
+      if (dense) sep_gemm_taps<SEP_MT>(acc, Xs + (dhalo - dpad) * XP, XP, p.w, p.cin_pad, cout_pad, cor, p.dense_k, p.dilation);
+      else sep_gemm(acc, wf, Xs, XP, p.w, p.cin_pad, cor);
+    }
     // prefetch what the NEXT GEMM of this wave needs while the epilogue below runs
     const bool more = cbase + SEP_PASS < cout_pad;
     const int con = more ? ((cbase + SEP_PASS + co_l < cout_pad) ? cbase + SEP_PASS + co_l : 0) : 0;
@@ -346,7 +419,7 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
     if (f_resadd && n_panes > 0) sep_load_w(wf, p.panes[0].w, p.panes[0].cin_pad, cor, 0);
     if (more) {
       nxt = sep_lane_params<EP>(p, con);
-      if (!f_resadd) sep_load_w(wf, p.w, p.cin_pad, con, 0);
+      if (!f_resadd && !dense) sep_load_w(wf, p.w, p.cin_pad, con, 0);
     }
     STAMP();
     if (DBG) {
@@ -440,7 +513,7 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) accp[mt][r] = bv;
       if (co_in) sep_gemm(accp, wf, Xr, XPr, pn.w, pn.cin_pad, cor);
-      if (more) sep_load_w(wf, p.w, p.cin_pad, con, 0);
+      if (more && !dense) sep_load_w(wf, p.w, p.cin_pad, con, 0);
 #pragma unroll
       for (int mt = 0; mt < SEP_MT; ++mt) {
         if (DBG) sep_dump(pn.acc_dbg, accp[mt], b, co, ecout, t0 + 32 * mt, h, eT, eTp);
@@ -490,7 +563,7 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
           }
         }
       }
-      if (more) sep_load_w(wf, p.w, p.cin_pad, con, 0);
+      if (more && !dense) sep_load_w(wf, p.w, p.cin_pad, con, 0);
 #pragma unroll
       for (int mt = 0; mt < SEP_MT; ++mt) {
         int z[16];
@@ -524,7 +597,8 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
 }
 
 static inline size_t sep_smem_bytes(const SepP& p, int WP, int TT) {
-  size_t xs = (size_t)TT * (p.cin_pad + 16);
+  const int dpad = p.dense_k > 1 ? (p.dense_k - 1) * p.dilation / 2 : 0, dhalo = (dpad + 3) & ~3;
+  size_t xs = (size_t)(TT + 2 * dhalo) * (p.cin_pad + 16);
   size_t xr = 0;
   for (int k = 0; k < p.n_panes; ++k) xr = std::max(xr, (size_t)TT * (p.panes[k].cin_pad + 16));
   size_t ws = std::max((size_t)256 * WP, (size_t)SEP_STG_BYTES);  // 256 window rows in either dilation mode
@@ -574,7 +648,7 @@ static void launch_sep_k(hipStream_t s, const SepP& p) {
 // all kernel-size instantiations of one (tile, debug) pair
 template <int TT, bool DBG>
 void launch_sep_inst(hipStream_t s, const SepP& p) {
-  if (p.dilation == 2) {
+  if (p.K > 0 && p.dilation == 2) {                         // depthwise dilation (for K == 0 `dilation` is the dense tap spacing)
     if (p.K == 87) launch_sep_k<87, 2, DBG, TT>(s, p);
     else if (p.K == 15) launch_sep_k<15, 2, DBG, TT>(s, p);
     return;

@@ -22,9 +22,9 @@ import torch
 from . import quant_math as Q
 from .topology import ModelCfg, conv_plan
 
-MAGIC, VERSION = 0x52534151, 3
+MAGIC, VERSION = 0x52534151, 4
 OP_QUANT_IN, OP_DW, OP_PW, OP_DENSE, OP_LOGSOFTMAX, OP_REQUANT = range(6)
-F_RELU, F_MASK_OUT, F_EXACT_Z, F_LOGITS, F_RESADD = 1, 2, 4, 8, 16
+F_RELU, F_MASK_OUT, F_EXACT_Z, F_LOGITS, F_RESADD, F_TAPMAJOR = 1, 2, 4, 8, 16, 32
 DT_S8, DT_U8, DT_F32, DT_I32 = range(4)
 MAX_PANES, MAX_OUTS = 12, 3
 COUT_ALIGN, CIN_ALIGN = 128, 128
@@ -167,6 +167,8 @@ class Packer:
                 kind = OP_DW if s.role == 'dw' else (OP_PW if s.kernel == 1 else OP_DENSE)
                 op = dict(kind=kind, flags=F_MASK_OUT | (F_RELU if s.relu_after else 0) | (F_EXACT_Z if exact else 0),
                           site=s, inp=cons, wi=wi, bint=bint, s_b=s_b, panes=[], in_unsigned=in_unsigned)
+                if kind == OP_DENSE and s.stride == 1 and (s.kernel & 1) and 2 * s.padding == s.dilation * (s.kernel - 1):
+                    op['flags'] |= F_TAPMAJOR                # runs as taps shifted 1x1 GEMMs on the tile kernel
                 self.ops.append(op)
                 self.sites.append((len(self.ops) - 1, -1))
                 cur = _Value('acc', len(self.ops) - 1, s.cout, dom, s_b)
@@ -287,7 +289,7 @@ class Packer:
         out[:a.shape[0]] = a
         return out
 
-    def _pack_weights(self, kind, wi):
+    def _pack_weights(self, kind, wi, tap_major=False):
         cout = wi.shape[0]
         cp = _rup(cout, COUT_ALIGN)
         if kind == OP_DW:
@@ -302,6 +304,8 @@ class Packer:
         w[:cout, :, :cin] = wi.permute(0, 2, 1).to(torch.int8)
         if kind == OP_PW:
             return self._put(fragment_order(w[:, 0, :].numpy()))
+        if tap_major:                                        # one fragment-ordered [cout_pad][cin_pad] matrix per tap
+            return self._put(np.concatenate([fragment_order(np.ascontiguousarray(w[:, t, :].numpy())) for t in range(k)]))
         return self._put(w.numpy())
 
     def _vec(self, t, rows, dtype, fill=0):
@@ -321,7 +325,7 @@ class Packer:
             cp = _rup(cout, COUT_ALIGN)
             w_off = bias_off = m_off = sb_off = 0
             if kind in (OP_DW, OP_PW, OP_DENSE):
-                w_off = self._pack_weights(kind, op['wi'])
+                w_off = self._pack_weights(kind, op['wi'], bool(op['flags'] & F_TAPMAJOR))
                 bias_off = self._vec(op['bint'].to(torch.int32), cp, np.int32)
                 sb_off = self._vec(op['s_b'], cp, np.float32, 1.0)
                 if op['flags'] & F_RESADD:
