@@ -29,7 +29,7 @@ extern "C" {
 #define QASR_ERR_UNSUPPORTED 4
 
 #define QASR_BLOB_MAGIC 0x52534151u /* "QASR" */
-#define QASR_BLOB_VERSION 4u
+#define QASR_BLOB_VERSION 5u
 
 /* ---- packed model ("blob") layout, produced by qasr/pack.py --------------------------------
  * header | tensor table | op table | data (int8 weights, int32 biases, f64 requant multipliers,
@@ -113,7 +113,9 @@ typedef struct qasr_op_desc {
   uint64_t w_off;              /* s8 weights: DW [c][kpad4]; PW cout_pad x cin_pad in MFMA fragment order (see
                                   qasr_pw_conv_acc); DENSE [cout_pad][k][cin_pad] */
   uint64_t bias_off;           /* i32 [cout] (0 = none) */
-  uint64_t m_off;              /* RESADD: f64 [cout] multiplier of the main accumulator towards S */
+  uint64_t m_off;              /* RESADD: f64 [cout] multiplier of the main accumulator towards S;
+                                  DW ops: s8 [cout][kpad4 + 32], the taps again behind 8 zero bytes and followed by zeros
+                                  (per-lane pre-shifted tap streams of the MFMA depthwise stage) */
   uint64_t sb_off;             /* f32 [cout] conv output scale s_w[c]*s_x */
   int32_t qlo, qhi;            /* RESADD clamp of res_act */
   float in_inv_scale;          /* QUANT_IN: fl32(1/s) ; int32 range in qlo/qhi */

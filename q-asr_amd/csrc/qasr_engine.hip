@@ -370,6 +370,7 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
     const TensorRT& din = e->tens[d.in];
     p.x = (const int8_t*)din.ptr;
     p.wdw = dev_at<int8_t>(e, d.w_off);
+    p.wdw2 = dev_at<int8_t>(e, d.m_off);                  // DW ops carry their zero-margined tap array in m_off
     p.bias_dw = dev_at<int32_t>(e, d.bias_off);
     p.m_dw = dev_at<double>(e, d.outs[0].m_off);
     p.dw_acc_dbg = (e->debug && !e->acc_dbg[di].empty()) ? e->acc_dbg[di][0] : nullptr;

@@ -72,6 +72,7 @@ struct SepP {             // fused separable layer: depthwise stencil -> QuantAc
   // depthwise stage (absent when K == 0: the 1x1 conv reads `x` directly)
   const int8_t* x;        // [B][cin][Tp]   input of the depthwise conv (or of the 1x1 conv when K == 0)
   const int8_t* wdw;      // [cin][kpad4]
+  const int8_t* wdw2;     // [cin][kpad4 + 32]: the same taps behind 8 zero bytes and followed by zeros (MFMA depthwise)
   const int32_t* bias_dw; // [cin_pad]  128*sum(w) for u8 inputs
   const double* m_dw;     // [cin_pad]  requant of the dw accumulator towards the 1x1 conv's QuantAct
   int32_t* dw_acc_dbg;    // optional i32 [B][cin][Tp]

@@ -43,6 +43,7 @@ struct SepGeo {
   static constexpr int HALO = (PAD + 15) / 16 * 16;        // staged halo, 16-B granular (stream samples)
   static constexpr int D = HALO - PAD;                      // byte offset of the first tap inside the staged window
   static constexpr int KP4 = (K + 3) / 4;
+  static constexpr int KS = 4 * KP4 + 32;                   // row pitch of the zero-margined tap array (8 B in front)
   static constexpr int WLEN = TT / DIL + 2 * HALO;      // staged bytes per LDS row
   static constexpr int WP = WLEN + 16;                      // LDS row pitch of the window
   static constexpr int NX = KP4 + 5;                        // window dwords a lane reads for 16 outputs
@@ -315,6 +316,81 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
     fetch(0);
     for (int c0 = 0; c0 < p.cin; c0 += CH) {
       const int nch = min(CH, p.cin - c0);
+      if constexpr (DIL == 1) {
+        // ---- depthwise taps on the matrix cores: v_mfma_i32_4x4x4_16B_i8 = 16 independent 4x4x4 products, block =
+        // channel.  With A[i][k] = win[f0 + D + m0 + 4i + k] and B[k][j] = w[m0 + k - j] (0 outside the taps) the block
+        // accumulates out[f0 + 4i + j] over the 4 taps m0-j .. m0-j+3; m0 advances by 4 per instruction.  Lane l of a
+        // group: channel l >> 2, A row i = l & 3 (one aligned LDS dword), B column j = l & 3 (one dword of the lane's
+        // own pre-shifted tap stream, read unaligned from the zero-margined tap array), D register v = row i.
+        // Wave w owns rows [32w, 32w + 32) of the chunk: 2 groups of 16 channels x TT/16 frame tiles.
+        constexpr int MS = -(G::D & 3);                      // first m0: keeps the A dwords 4-byte aligned
+        constexpr int NS = (K + 3 - MS + 3) / 4;             // instructions per 16-frame tile
+        constexpr int NZ = 4 * (TT / 16);                    // outputs per lane and group
+        const int cb = lane >> 2, jl = lane & 3;
+        // taps of both groups of this wave: requested before the barrier they do not depend on
+        // the lane's tap stream starts at byte 8 + MS - jl of its channel's row: whole dwords are fetched with wide
+        // loads (rows are 4-byte aligned) and funnel-shifted into place once per chunk
+        constexpr int NR = (NS + 1 + 3) / 4 * 4;
+        const int e0 = 8 + MS - jl, tq = e0 >> 2, tsh = e0 & 3;
+        v4i raw[2][NR / 4];
+        int biasg[2];
+        double Mg[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int row = 32 * wave + 16 * g + cb;
+          const int c = c0 + min(row, nch - 1);
+          const v4i* tp = (const v4i*)((const unsigned char*)p.wdw2 + (size_t)c * G::KS + 4 * tq);
+#pragma unroll
+          for (int i = 0; i < NR / 4; ++i) raw[g][i] = tp[i];
+          biasg[g] = p.bias_dw[c];
+          Mg[g] = p.m_dw[c];
+        }
+        if (c0) __syncthreads();                             // previous chunk's window fully consumed
+        commit(c0);
+        __syncthreads();
+        if (c0 + CH < p.cin) fetch(c0 + CH);                 // next chunk's window travels during this chunk's math
+        STAMP();
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int row = 32 * wave + 16 * g + cb;
+          if (32 * wave + 16 * g >= nch) break;              // wave-uniform: group entirely beyond the chunk
+          const bool row_ok = row < nch;
+          const int c = c0 + row;
+          unsigned tw[NS];
+#pragma unroll
+          for (int st = 0; st < NS; ++st)
+            tw[st] = __builtin_amdgcn_alignbyte((unsigned)raw[g][(st + 1) >> 2][(st + 1) & 3], (unsigned)raw[g][st >> 2][st & 3], tsh);
+          int z[NZ];
+#pragma unroll
+          for (int ft = 0; ft < TT / 16; ++ft) {
+            v4i acc = {biasg[g], biasg[g], biasg[g], biasg[g]};
+            const unsigned* ap = (const unsigned*)(Ws + min(row, nch - 1) * G::WP + 16 * ft + (G::D + MS) + 4 * jl);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)ap[st], (int)tw[st], acc, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) z[4 * ft + v] = acc[v];
+          }
+          // z[4 ft + v] is local frame 16 ft + 4 v + jl of channel c
+          if (DBG && p.dw_acc_dbg && row_ok) {
+#pragma unroll
+            for (int o = 0; o < NZ; ++o) {
+              const int f = 16 * (o >> 2) + 4 * (o & 3) + jl;
+              if (t0 + f < eT) p.dw_acc_dbg[((size_t)b * p.cin + c) * eTp + t0 + f] = z[o];
+            }
+          }
+          int qv[NZ];
+          requant_batch<NZ>(qv, z, Mg[g], dw_lo, dw_hi);
+          if (row_ok) {
+#pragma unroll
+            for (int o = 0; o < NZ; ++o) {
+              const int f = 16 * (o >> 2) + 4 * (o & 3) + jl;
+              Xs[f * XP + c] = (unsigned char)((t0 + f < dlim) ? qv[o] : 0);
+            }
+          }
+        }
+        STAMP();
+        continue;
+      }
       // taps / parameters of this thread's first task of the chunk: issued before the barrier they do not depend on
       const int task0 = tid;
       const bool has0 = task0 < nch * SEP_TPC;

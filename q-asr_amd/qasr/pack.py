@@ -22,7 +22,7 @@ import torch
 from . import quant_math as Q
 from .topology import ModelCfg, conv_plan
 
-MAGIC, VERSION = 0x52534151, 4
+MAGIC, VERSION = 0x52534151, 5
 OP_QUANT_IN, OP_DW, OP_PW, OP_DENSE, OP_LOGSOFTMAX, OP_REQUANT = range(6)
 F_RELU, F_MASK_OUT, F_EXACT_Z, F_LOGITS, F_RESADD, F_TAPMAJOR = 1, 2, 4, 8, 16, 32
 DT_S8, DT_U8, DT_F32, DT_I32 = range(4)
@@ -330,6 +330,12 @@ class Packer:
                 sb_off = self._vec(op['s_b'], cp, np.float32, 1.0)
                 if op['flags'] & F_RESADD:
                     m_off = self._vec(Q.requant_multiplier(op['s_b'], op['S']), cp, np.float64, 0.0)
+                elif kind == OP_DW:                          # zero-margined tap rows for the MFMA depthwise stage
+                    wi = op['wi']
+                    k = wi.shape[2]
+                    w2 = np.zeros((wi.shape[0], _rup(k, 4) + 32), dtype=np.int8)
+                    w2[:, 8:8 + k] = wi[:, 0, :].to(torch.int8).numpy()
+                    m_off = self._put(w2)
             elif kind == OP_REQUANT and op.get('s_b') is not None:
                 sb_off = self._vec(op['s_b'], cp, np.float32, 1.0)
             outs = b''
