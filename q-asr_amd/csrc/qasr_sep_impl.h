@@ -361,14 +361,22 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
           for (int st = 0; st < NS; ++st)
             tw[st] = __builtin_amdgcn_alignbyte((unsigned)raw[g][(st + 1) >> 2][(st + 1) & 3], (unsigned)raw[g][st >> 2][st & 3], tsh);
           int z[NZ];
+          {
+            // TT/16 frame tiles = independent accumulation chains, interleaved so that no MFMA waits for its predecessor
+            v4i acc[TT / 16];
 #pragma unroll
-          for (int ft = 0; ft < TT / 16; ++ft) {
-            v4i acc = {biasg[g], biasg[g], biasg[g], biasg[g]};
-            const unsigned* ap = (const unsigned*)(Ws + min(row, nch - 1) * G::WP + 16 * ft + (G::D + MS) + 4 * jl);
+            for (int ft = 0; ft < TT / 16; ++ft) acc[ft] = (v4i){biasg[g], biasg[g], biasg[g], biasg[g]};
+            const unsigned* ap = (const unsigned*)(Ws + min(row, nch - 1) * G::WP + (G::D + MS) + 4 * jl);
 #pragma unroll
-            for (int st = 0; st < NS; ++st) acc = __builtin_amdgcn_mfma_i32_4x4x4i8((int)ap[st], (int)tw[st], acc, 0, 0, 0);
+            for (int st = 0; st < NS; ++st) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) z[4 * ft + v] = acc[v];
+              for (int ft = 0; ft < TT / 16; ++ft)
+                acc[ft] = __builtin_amdgcn_mfma_i32_4x4x4i8((int)ap[4 * ft + st], (int)tw[st], acc[ft], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ft = 0; ft < TT / 16; ++ft)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) z[4 * ft + v] = acc[ft][v];
           }
           // z[4 ft + v] is local frame 16 ft + 4 v + jl of channel c
           if (DBG && p.dw_acc_dbg && row_ok) {
