@@ -292,3 +292,16 @@ def test_odd_sizes_against_oracle(eng, golden_dir, family):
             assert np.array_equal(tok[b, :n], want['tokens'][b, :n]), (B, T, lens, b)
             np.testing.assert_allclose(logp[b, :n], want['log_probs'][b, :n], rtol=1e-4, atol=5e-5)
     e.close()
+
+
+def test_engine_rejects_foreign_blob(eng, golden_dir):
+    """A blob of another format version (or garbage) must fail loudly at create time, not run with a wrong layout."""
+    d, meta = _load(golden_dir, 'net_miniq_w8a8')
+    cfg = _cfg('net_miniq_w8a8')
+    blob, _ = pack.pack_model(cfg, synth.make_state_dict(cfg, meta['seed']), d['act_min'], d['act_max'], 8, 8)
+    old = bytearray(blob)
+    old[4:8] = (int.from_bytes(blob[4:8], 'little') - 1).to_bytes(4, 'little')      # header: magic, version, ...
+    with pytest.raises(eng.QasrError):
+        eng.Engine(bytes(old), 0)
+    with pytest.raises(eng.QasrError):
+        eng.Engine(b'\0' * 4096, 0)
