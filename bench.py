@@ -191,6 +191,7 @@ def main():
     ap.add_argument('--tile', type=int, default=0, choices=[0, 32, 64],
                     help='k_sep frames per work-group: 32 = lowest single-step latency, 64 = less weight/halo traffic '
                          'per frame but half the work-groups; 0 = 64 when more than one step is in flight')
+    ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel instead of replaying the captured hipGraph')
     ap.add_argument('--whole-utterance', action='store_true', help='use the k_utt kernels (one work-group per utterance)')
     ap.add_argument('--streams', type=int, default=int(os.environ.get('QASR_BENCH_STREAMS', 4)),
                     help='independent steps in flight per GPU (each on its own HIP stream + engine arena)')
@@ -238,7 +239,8 @@ def main():
     # HIP stream with its own engine arena (kernels of different steps overlap each other's launch gaps and tails)
     S = max(1, args.streams)
     tile = args.tile or (64 if S > 1 else 32)
-    engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance, wide_tiles=(tile == 64)) for _ in range(S)]
+    engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance, wide_tiles=(tile == 64),
+                          graph=not args.no_graph) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     eng = engs[0]
     log(f'{S} engine(s) ready ({len(blob) / 1e6:.1f} MB blob); warm-up')
@@ -248,11 +250,20 @@ def main():
     T_out = eng.out_frames(engine.load_library().qasr_frontend_frames(SAMPLES, 16))
     gathered = [torch.empty(BATCH, T_out, dtype=torch.int32, device=comm_dev) for _ in range(world)] if rank == 0 else None
 
+    # every step in flight owns its buffers (features, lengths, tokens): stable pointers let the engine replay its
+    # forward as one hipGraph launch instead of ~90 kernel launches
+    T_pad = engine.load_library().qasr_frontend_frames(SAMPLES, 16)
+    lib_ws = engine.load_library().qasr_frontend_workspace_bytes(BATCH, SAMPLES, 64)
+    bufs = [dict(fe=(torch.empty(BATCH, 64, T_pad, device=dev), torch.empty(BATCH, dtype=torch.int32, device=dev),
+                     torch.empty(max(lib_ws, 16), dtype=torch.uint8, device=dev)),
+                 out=(None, torch.empty(BATCH, T_out, dtype=torch.int32, device=dev),
+                      torch.empty(BATCH, dtype=torch.int32, device=dev))) for _ in range(S)]
+
     def step(i):
         k = i % S
         with torch.cuda.stream(streams[k]):
-            feats, flen = engine.frontend_mel(audio, alen, fb, window, 0.97, 16)
-            _, tokens, _ = engs[k].forward(feats, flen, want_logp=False)
+            feats, flen = engine.frontend_mel(audio, alen, fb, window, 0.97, 16, out=bufs[k]['fe'])
+            _, tokens, _ = engs[k].forward(feats, flen, want_logp=False, out=bufs[k]['out'])
             done = torch.cuda.Event()
             done.record(streams[k])
         if world > 1:
@@ -295,7 +306,7 @@ def main():
         'config': {'workload': 'QuartzNet15x5Base-En w8a8 percentile=99.996, bs=32/GPU, 5 s synthetic 16 kHz audio '
                                '(500 mel frames): HIP mel front-end + integer encoder + CTC decoder + greedy argmax',
                    'global_batch': BATCH * world, 'seq_len': FRAMES, 'weights': 'random-init (qasr.synth, seed 0)',
-                   'steps_in_flight': S, 'kernels': 'k_utt' if args.whole_utterance else f'k_sep, {tile}-frame tiles', 'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + token gather' if world > 1 else ''),
+                   'steps_in_flight': S, 'hip_graph': not args.no_graph, 'kernels': 'k_utt' if args.whole_utterance else f'k_sep, {tile}-frame tiles', 'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + token gather' if world > 1 else ''),
                    'wer': 'not measurable here: no LibriSpeech / checkpoint in the image'},
     }
 

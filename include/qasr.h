@@ -135,7 +135,9 @@ typedef struct qasr_engine qasr_engine;
  * bit 2 selects the whole-utterance kernels (k_utt: one work-group per utterance and layer, T <= 256 frames) instead of
  * the 32-frame tiles of k_sep - same results, meant for many steps in flight;
  * bit 3 makes k_sep use 64-frame tiles (half the weight / halo traffic per frame and half as many work-groups per
- * launch: faster when several steps are in flight on separate streams, slower for a single step). */
+ * launch: faster when several steps are in flight on separate streams, slower for a single step);
+ * bit 4 replays the forward as a hipGraph: the second forward with the same shape and the same five buffer pointers is
+ * captured, later ones are one hipGraphLaunch (a new pointer set or shape starts over; ignored with bits 0/1). */
 int qasr_engine_create(const void* blob, size_t blob_bytes, int device, int debug, qasr_engine** out);
 void qasr_engine_destroy(qasr_engine* e);
 

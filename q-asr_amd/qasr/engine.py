@@ -79,7 +79,8 @@ def _ptr(t):
 class Engine:
     """One packed model on one GPU (qasr_engine_*)."""
 
-    def __init__(self, blob: bytes, device=0, debug=False, timing=False, whole_utterance=False, wide_tiles=False):
+    def __init__(self, blob: bytes, device=0, debug=False, timing=False, whole_utterance=False, wide_tiles=False,
+                 graph=False):
         lib = load_library()
         if not torch.cuda.is_available():
             raise QasrError('no GPU: the integer engine needs an MI355X (there is no CPU fallback)')
@@ -88,7 +89,7 @@ class Engine:
         self._blob = blob
         self._h = C.c_void_p()
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
-        _check(lib.qasr_engine_create(C.cast(buf, C.c_void_p), len(blob), device, int(bool(debug)) | (2 if timing else 0) | (4 if whole_utterance else 0) | (8 if wide_tiles else 0),
+        _check(lib.qasr_engine_create(C.cast(buf, C.c_void_p), len(blob), device, int(bool(debug)) | (2 if timing else 0) | (4 if whole_utterance else 0) | (8 if wide_tiles else 0) | (16 if graph else 0),
                                       C.byref(self._h)),
                'qasr_engine_create')
         self.debug = debug
@@ -111,16 +112,19 @@ class Engine:
     def out_frames(self, T):
         return self.lib.qasr_engine_out_frames(self._h, int(T))
 
-    def forward(self, feats: torch.Tensor, lens: torch.Tensor, want_logp=True, stream=None):
+    def forward(self, feats: torch.Tensor, lens: torch.Tensor, want_logp=True, stream=None, out=None):
         """feats f32 [B, feat_in, T] (cuda, contiguous), lens [B] -> (log_probs [B,T',C], tokens [B,T'], enc_len [B])."""
         assert feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 3 and feats.shape[1] == self.feat_in
         feats = feats.contiguous()
         lens32 = lens.to(device=feats.device, dtype=torch.int32).contiguous()
         B, _, T = feats.shape
         To = self.out_frames(T)
-        logp = torch.empty(B, To, self.n_classes, device=feats.device, dtype=torch.float32) if want_logp else None
-        tokens = torch.empty(B, To, device=feats.device, dtype=torch.int32)
-        enc_len = torch.empty(B, device=feats.device, dtype=torch.int32)
+        if out is not None:                                  # caller-owned (logp or None, tokens, enc_len): stable pointers
+            logp, tokens, enc_len = out
+        else:
+            logp = torch.empty(B, To, self.n_classes, device=feats.device, dtype=torch.float32) if want_logp else None
+            tokens = torch.empty(B, To, device=feats.device, dtype=torch.int32)
+            enc_len = torch.empty(B, device=feats.device, dtype=torch.int32)
         _check(self.lib.qasr_engine_forward(self._h, _stream_ptr(stream), _ptr(feats), _ptr(lens32), B, T,
                                             _ptr(logp), _ptr(tokens), _ptr(enc_len)), 'qasr_engine_forward')
         self.B, self.T = B, T
@@ -231,7 +235,7 @@ def requant(acc: torch.Tensor, M: torch.Tensor, lo, hi, sb=None, exact_z=False, 
 
 
 def frontend_mel(audio: torch.Tensor, lens: torch.Tensor, fb: torch.Tensor, window: torch.Tensor, preemph=0.97,
-                 pad_to=16):
+                 pad_to=16, out=None):
     """qasr_frontend_mel: audio f32 [B,S] (cuda), lens [B] samples, fb [n_mels,257], window [320]
     -> (features f32 [B,n_mels,T_pad], feature lengths i32 [B])."""
     lib = load_library()
@@ -240,14 +244,18 @@ def frontend_mel(audio: torch.Tensor, lens: torch.Tensor, fb: torch.Tensor, wind
     n_mels = fb.shape[0]
     dev = audio.device
     T_pad = lib.qasr_frontend_frames(S, pad_to)
-    feats = torch.empty(B, n_mels, T_pad, device=dev, dtype=torch.float32)
-    flens = torch.empty(B, device=dev, dtype=torch.int32)
+    if out is not None:                                      # caller-owned (features, lengths, workspace)
+        feats, flens, ws_out = out
+    else:
+        feats = torch.empty(B, n_mels, T_pad, device=dev, dtype=torch.float32)
+        flens = torch.empty(B, device=dev, dtype=torch.int32)
+        ws_out = None
     a = audio.contiguous()
     l32 = lens.to(device=dev, dtype=torch.int32).contiguous()
     fbd = fb.to(device=dev, dtype=torch.float32).contiguous()
     wd = window.to(device=dev, dtype=torch.float32).contiguous()
     ws_bytes = lib.qasr_frontend_workspace_bytes(B, S, n_mels)
-    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    ws = ws_out if ws_out is not None else torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
     _check(lib.qasr_frontend_mel(_stream_ptr(), _ptr(a), _ptr(l32), B, S, _ptr(fbd), _ptr(wd), n_mels,
                                  C.c_float(preemph), pad_to, _ptr(feats), _ptr(flens), _ptr(ws), ws.numel()),
            'qasr_frontend_mel')

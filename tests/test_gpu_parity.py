@@ -305,3 +305,35 @@ def test_engine_rejects_foreign_blob(eng, golden_dir):
         eng.Engine(bytes(old), 0)
     with pytest.raises(eng.QasrError):
         eng.Engine(b'\0' * 4096, 0)
+
+
+def test_graph_replay_matches_direct_launches(eng, golden_dir):
+    """Engine flag 16: the forward is captured into a hipGraph on the second call with the same buffers and replayed
+    afterwards; new buffers or a new shape start over.  Results must equal the kernel-by-kernel engine every time."""
+    d, meta = _load(golden_dir, 'net_quartznet_w8a8')
+    cfg = topology.quartznet15x5()
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    blob, _ = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    ref, g = eng.Engine(blob, 0), eng.Engine(blob, 0, graph=True, wide_tiles=True)
+    for B, T in ((8, 256), (8, 256), (3, 130)):
+        x = torch.from_numpy(synth.make_features(B, 64, T, 7 + T)).cuda()
+        lens = torch.tensor([T - 3 * i for i in range(B)], dtype=torch.int32).cuda()
+        lp0, tk0, el0 = ref.forward(x, lens)
+        To = g.out_frames(T)
+        out = (torch.empty(B, To, 29, device='cuda'), torch.empty(B, To, dtype=torch.int32, device='cuda'),
+               torch.empty(B, dtype=torch.int32, device='cuda'))
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for it in range(6):                                   # direct, capture, replay, replay, new pointer, default stream
+            x2 = x.clone() if it == 4 else x                 # a new input pointer forces a fresh capture cycle
+            out[1].zero_()
+            torch.cuda.synchronize()
+            if it < 5:
+                with torch.cuda.stream(side):
+                    lp, tk, el = g.forward(x2, lens, out=out)
+            else:                                             # the legacy default stream cannot be captured: direct launches
+                lp, tk, el = g.forward(x2, lens, out=out)
+            torch.cuda.synchronize()
+            assert torch.equal(tk, tk0) and torch.equal(lp, lp0) and torch.equal(el, el0), (B, T, it)
+    ref.close()
+    g.close()
