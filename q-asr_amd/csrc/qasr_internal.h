@@ -117,6 +117,7 @@ void launch_dense(hipStream_t s, const DenseP& p);
 bool sep_supported(int K, int dilation);
 void launch_sep(hipStream_t s, const SepP& p);
 void sep_kernel_label(const SepP& p, char* buf, size_t cap);
+int sep_tile_for(const SepP& p);
 bool utt_supported(int K, int dilation, int Tp, int cin_pad, int cin);
 void launch_utt(hipStream_t s, const SepP& p, int ep);   // ep: 0 plain, 1 rq32 (residual conv), 2 add32 (res_act)
 void launch_requant(hipStream_t s, const RequantP& p);

@@ -20,12 +20,19 @@ bool sep_supported(int K, int dilation) {
 void sep_kernel_label(const SepP& p, char* buf, size_t cap) {
   const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
   snprintf(buf, cap, "k_sep<%d, %d, %d, %s, %d>", p.K, p.K > 0 ? p.dilation : 1, sep_epilogue_class(p), dbg ? "true" : "false",
-           p.tile == 64 ? 64 : 32);
+           sep_tile_for(p));
+}
+
+// The generic epilogue (logits, raw int32 outs, several residual panes) does not fit the register file with two frame
+// tiles per wave (hundreds of spilled VGPRs): 1x1 ops of that class run with 32-frame tiles (QuartzNet decoder 32 -> 17 us).
+// Dense k > 1 convs keep the wide tile: halving their weight traffic outweighs the spills (Jasper 9.7 vs 9.9 ms).
+int sep_tile_for(const SepP& p) {
+  return (p.tile == 64 && (p.dense_k > 1 || sep_epilogue_class(p) != EP_GENERIC)) ? 64 : 32;
 }
 
 void launch_sep(hipStream_t s, const SepP& p) {
   const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
-  if (p.tile == 64) {
+  if (sep_tile_for(p) == 64) {
     if (dbg) launch_sep_inst<64, true>(s, p);
     else launch_sep_inst<64, false>(s, p);
   } else {
