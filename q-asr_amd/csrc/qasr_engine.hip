@@ -66,7 +66,7 @@ struct qasr_engine {
   std::vector<int> fused_dw;           // per op: index of the DW op fused into this PW op, or -1
   std::vector<char> skip;              // per op: launched as part of the following op
   bool wide_tiles = false;             // k_sep with 64-frame tiles (throughput mode: bit 3 of `debug`, or QASR_WIDE_TILES=1)
-  bool use_utt = true;                 // throughput mode: whole-utterance kernels (QASR_NO_UTT=1 disables)
+  bool use_utt = false;                // whole-utterance kernels k_utt (bit 2 of `debug`, or QASR_UTT=1)
   std::vector<char> utt;               // per op: 0 = k_sep, 1 = k_utt plain, 2 = k_utt residual pair (rq32 + add32)
   int32_t* r32 = nullptr;              // scratch [B][max cout][Tp] of the residual pair
   // hipGraph replay (bit 4 of `debug`): the whole forward of one (shape, buffer set) is captured once and re-launched
