@@ -537,22 +537,57 @@ void launch_dense(hipStream_t s, const DenseP& p) {
 }
 
 // ------------------------------------------------------------------------------------------------ requant (stand-alone)
-__global__ void k_requant(RequantP p) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int row = blockIdx.y;                       // b * C + c
-  if (t >= p.Tp) return;
-  int b = row / p.C, c = row - b * p.C;
-  size_t idx = (size_t)row * p.Tp + t;
-  int acc = p.in_is_i32 ? ((const int*)p.in)[idx] : (int)((const int8_t*)p.in)[idx];
-  bool relu = p.flags & QASR_F_RELU;
-  int z = (p.flags & QASR_F_EXACT_Z) ? z_roundtrip(acc, p.sb[c], relu) : (relu ? max(acc, 0) : acc);
-  bool live = t < p.T && (!(p.flags & QASR_F_MASK_OUT) || t < p.lens[b]);
-  int v = live ? out_value(z, p.out, p.out.mode == 1 ? p.out.mtab[c] : 0.0) : 0;
-  ((int8_t*)p.out.ptr)[idx] = (int8_t)v;
+// One lane = 16 consecutive frames of one (utterance, channel) row: wide loads, the production requant_batch
+// (float32 fast path + fp64 fallback), one 16-byte store.
+__global__ void __launch_bounds__(256) k_requant(RequantP p) {
+  const int tq = blockIdx.x * blockDim.x + threadIdx.x;      // 16-frame group along time
+  const int row = blockIdx.y;                                 // b * C + c
+  if (tq * 16 >= p.Tp) return;
+  const int b = row / p.C, c = row - b * p.C;
+  const size_t idx = (size_t)row * p.Tp + 16 * tq;
+  int acc[16];
+  if (p.in_is_i32) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const v4i v = *(const v4i*)((const int*)p.in + idx + 4 * g);
+      acc[4 * g] = v[0]; acc[4 * g + 1] = v[1]; acc[4 * g + 2] = v[2]; acc[4 * g + 3] = v[3];
+    }
+  } else {
+    const v4i v = *(const v4i*)((const int8_t*)p.in + idx);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = (int)(int8_t)((unsigned)v[i >> 2] >> (8 * (i & 3)));
+  }
+  const bool relu = p.flags & QASR_F_RELU;
+  int z[16];
+  if (p.flags & QASR_F_EXACT_Z) {
+    const float sb = p.sb[c];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = z_roundtrip(acc[i], sb, relu);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = relu ? max(acc[i], 0) : acc[i];
+  }
+  int q[16];
+  if (p.out.mode == 2) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q[i] = z[i];
+  } else {
+    requant_batch<16>(q, z, p.out.mode == 1 ? p.out.mtab[c] : p.out.m, p.out.lo, p.out.hi);
+  }
+  const int lim = (p.flags & QASR_F_MASK_OUT) ? min(p.T, p.lens[b]) : p.T;
+  v4i pk;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    int v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (16 * tq + 4 * g + i < lim) ? q[4 * g + i] : 0;
+    pk[g] = (int)pack4(v[0], v[1], v[2], v[3]);
+  }
+  *(v4i*)((int8_t*)p.out.ptr + idx) = pk;
 }
 void launch_requant(hipStream_t s, const RequantP& p) {
-  dim3 g((p.Tp + 255) / 256, p.B * p.C);
-  hipLaunchKernelGGL(k_requant, g, dim3(256), 0, s, p);
+  dim3 g((p.Tp / 16 + 63) / 64, p.B * p.C);
+  hipLaunchKernelGGL(k_requant, g, dim3(64), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------ log-softmax + argmax

@@ -337,3 +337,29 @@ def test_graph_replay_matches_direct_launches(eng, golden_dir):
             assert torch.equal(tk, tk0) and torch.equal(lp, lp0) and torch.equal(el, el0), (B, T, it)
     ref.close()
     g.close()
+
+
+def test_requant_fast_path_adversarial(eng):
+    """qasr_requant runs the production requant_batch (float32 product, tie-window vote, fp64 fallback).  Inputs built to
+    sit ON and next to rounding ties (z*M = k + 1/2 exactly, and one float32 ulp away from it), beyond the clamp range,
+    and with multipliers whose float32 image rounds the other way - against numpy fp64 round-half-even."""
+    rng = np.random.default_rng(11)
+    C, T = 64, 256
+    M = np.empty(C)
+    M[:16] = 0.5                                              # z odd -> exact ties
+    M[16:32] = 2.0 ** -rng.integers(1, 12, 16) * rng.integers(1, 64, 16)          # dyadic: many exact ties
+    M[32:48] = (rng.integers(1 << 30, 1 << 31, 16).astype(np.float64)) * 2.0 ** -rng.integers(31, 45, 16)  # (m, e) like batch_frexp
+    M[48:] = rng.random(16) * 0.05
+    z = rng.integers(-(1 << 22), 1 << 22, size=(2, C, T)).astype(np.int32)
+    z[:, :, :64] = rng.integers(-4000, 4000, size=(2, C, 64))                      # small: products inside the ranges
+    k = rng.integers(-200, 200, size=(2, 16, 64))
+    z[:, 32:48, 64:128] = np.rint((k + 0.5) / M[32:48, None]).astype(np.int32)     # as close to a tie as integers allow
+    for lo, hi in ((-128, 127), (0, 255), (-32, 31), (-256, 255)):
+        want = np.clip(np.rint(z.astype(np.float64) * M[None, :, None]), lo, hi)
+        got = eng.requant(torch.from_numpy(z).cuda(), torch.from_numpy(M), lo, hi).cpu().numpy()
+        got = got.view(np.uint8).astype(np.int64) if hi > 127 else got.astype(np.int64)
+        if lo < 0 and hi > 127:                              # 9-bit signed range does not fit a byte: compare where it does
+            ok = (want >= -128) & (want <= 127)
+            assert np.array_equal(got.astype(np.int8)[ok], want.astype(np.int64)[ok].astype(np.int8))
+        else:
+            assert np.array_equal(got, want.astype(np.int64)), (lo, hi, int((got != want).sum()))
