@@ -306,7 +306,7 @@ def main():
     result = {
         'metric': 'RTFx (audio-sec/wall-sec) QuartzNet15x5 int8 bs32', 'value': audio_s / dt, 'unit': 'audio-s/wall-s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 's8 x s8 -> i32 (MFMA), f64 requant',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8 (s8 x s8 -> i32 on MFMA; float32/float64 fixed-point requant)',
         'data': 'synthetic',
         'config': {'workload': 'QuartzNet15x5Base-En w8a8 percentile=99.996, bs=32/GPU, 5 s synthetic 16 kHz audio '
                                '(500 mel frames): HIP mel front-end + integer encoder + CTC decoder + greedy argmax',
