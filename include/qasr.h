@@ -29,7 +29,7 @@ extern "C" {
 #define QASR_ERR_UNSUPPORTED 4
 
 #define QASR_BLOB_MAGIC 0x52534151u /* "QASR" */
-#define QASR_BLOB_VERSION 5u
+#define QASR_BLOB_VERSION 6u
 
 /* ---- packed model ("blob") layout, produced by qasr/pack.py --------------------------------
  * header | tensor table | op table | data (int8 weights, int32 biases, f64 requant multipliers,
@@ -80,8 +80,10 @@ enum {
   QASR_F_EXACT_Z = 1u << 2,     /* |acc| may reach 2^22: take z through the float32 round trip (quant_utils.py:187) */
   QASR_F_LOGITS = 1u << 3,      /* decoder: emit f32 logits = fl32(fl32(acc)*s_b) as [B][T][C] */
   QASR_F_RESADD = 1u << 4,      /* res_act: q = clamp(rq(main) + rq(pane) ...) sequentially over panes */
-  QASR_F_TAPMAJOR = 1u << 5     /* DENSE op (stride 1, 'same' padding): weights stored as one MFMA-fragment-ordered
+  QASR_F_TAPMAJOR = 1u << 5,    /* DENSE op (stride 1, 'same' padding): weights stored as one MFMA-fragment-ordered
                                    [cout_pad][cin_pad] matrix per tap; runs on the k_sep tile kernel */
+  QASR_F_WIDE_RQ = 1u << 6      /* some |acc * m| of this op may reach 2^30 (a QuantAct calibrated on near-silence): the
+                                   requantisation must clamp in the double domain (k_sep), not on the low word (k_sep2) */
 };
 
 #define QASR_MAX_PANES 12

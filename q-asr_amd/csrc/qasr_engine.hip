@@ -67,6 +67,7 @@ struct qasr_engine {
   std::vector<char> skip;              // per op: launched as part of the following op
   bool wide_tiles = false;             // k_sep with 64-frame tiles (throughput mode: bit 3 of `debug`, or QASR_WIDE_TILES=1)
   bool use_utt = false;                // whole-utterance kernels k_utt (bit 2 of `debug`, or QASR_UTT=1)
+  int sep_gen = 2;                     // 2: k_sep2 where it has the shape; 1 (QASR_SEP_GEN=1): k_sep everywhere (A/B runs)
   std::vector<char> utt;               // per op: 0 = k_sep, 1 = k_utt plain, 2 = k_utt residual pair (rq32 + add32)
   int32_t* r32 = nullptr;              // scratch [B][max cout][Tp] of the residual pair
   // hipGraph replay (bit 4 of `debug`): the whole forward of one (shape, buffer set) is captured once and re-launched
@@ -314,6 +315,7 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
   e->debug = (debug & 1) != 0;
   e->fuse = getenv("QASR_NO_FUSE") == nullptr;
   e->legacy_pw = getenv("QASR_LEGACY_PW") != nullptr;
+  if (const char* g = getenv("QASR_SEP_GEN")) e->sep_gen = atoi(g) == 1 ? 1 : 2;
   // whole-utterance kernels (k_utt) are opt-in: bit 2 of `debug` or QASR_UTT=1 (throughput experiments)
   e->use_utt = (debug & 4) != 0 || getenv("QASR_UTT") != nullptr;
   e->wide_tiles = (debug & 8) != 0 || getenv("QASR_WIDE_TILES") != nullptr;
@@ -370,6 +372,7 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
   p.cin_pad = rup(p.cin, 128);
   p.n_panes = (int)op.n_panes;
   p.tile = e->wide_tiles ? 64 : 32;
+  p.gen = e->sep_gen;
   fill_panes(e, oi, op, p.panes);
   fill_epi(e, oi, op, p.e);
   const int di = e->fused_dw[oi];
@@ -388,6 +391,7 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
     p.dilation = (int)d.dilation;
     p.x_unsigned = din.d.dtype == QASR_DT_U8;
     p.pw_unsigned = 0;
+    if (d.flags & QASR_F_WIDE_RQ) p.gen = 1;                // k_sep2 clamps on the low word of the rounded product
   } else {
     p.x = (const int8_t*)tin.ptr;
     p.K = 0;
@@ -476,7 +480,8 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
           p.n_panes = 0;
           launch_utt(s, p, 2);
         } else {
-          launch_sep(s, p);
+          int rc = launch_sep(s, p);
+          if (rc) return fail(rc, "op %u: no k_sep instantiation for K=%d dilation=%d (or bad launch shape)", oi, p.K, p.dilation);
         }
         break;
       }
@@ -497,7 +502,8 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
       if (op.flags & QASR_F_TAPMAJOR) {                     // stride-1 'same' dense conv: taps shifted 1x1 GEMMs on the tile kernel
         SepP p{};
         build_sep(e, oi, p);
-        launch_sep(s, p);
+        int rc = launch_sep(s, p);
+        if (rc) return fail(rc, "op %u: dense conv has no k_sep launch shape", oi);
         break;
       }
       DenseP p{};
@@ -748,7 +754,8 @@ int qasr_pw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t
   p.e.cout = cout;
   p.e.B = B;
   p.e.lens = (const int32_t*)z;
-  launch_sep((hipStream_t)stream, p);
+  int lrc = launch_sep((hipStream_t)stream, p);
+  if (lrc) return fail(lrc, "pw_conv_acc: launch rejected");
   HIPCHK(hipGetLastError());
   return QASR_OK;
 }

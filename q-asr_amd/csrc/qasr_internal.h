@@ -83,7 +83,8 @@ struct SepP {             // fused separable layer: depthwise stencil -> QuantAc
   const int8_t* w;        // [cout_pad][cin_pad]
   const int32_t* bias;    // [cout_pad]
   int cin, cin_pad, pw_unsigned, n_panes;
-  int dense_k, pad3_;     // > 1: dense conv with that many taps (K == 0 kernels; `w` tap-major, `dilation` = tap spacing)
+  int dense_k, gen;       // dense_k > 1: dense conv with that many taps (K == 0 kernels; `w` tap-major, `dilation` = tap spacing);
+                          // gen: 2 = route to k_sep2 where it has the shape (engine default), else k_sep
   const int32_t* r32;     // k_utt EP_ADD32: res_act operand rint(acc_res * M_res) of the block's residual conv
   long long* prof;        // diagnostics: s_memtime stamps of work-group (0,0,0), wave 0 (qasr_debug_prof)
   PaneP panes[QASR_MAX_PANES];
@@ -115,7 +116,7 @@ void launch_dw(hipStream_t s, const DwP& p);
 void launch_pw(hipStream_t s, const PwP& p);
 void launch_dense(hipStream_t s, const DenseP& p);
 bool sep_supported(int K, int dilation);
-void launch_sep(hipStream_t s, const SepP& p);
+int launch_sep(hipStream_t s, const SepP& p);      // QASR_OK, or QASR_ERR_UNSUPPORTED / QASR_ERR_ARG without launching
 void sep_kernel_label(const SepP& p, char* buf, size_t cap);
 int sep_tile_for(const SepP& p);
 bool utt_supported(int K, int dilation, int Tp, int cin_pad, int cin);

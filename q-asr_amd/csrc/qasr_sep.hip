@@ -1,6 +1,7 @@
 // k_sep: host-side routing of the fused separable-layer kernel (qasr_sep_impl.h holds the kernel; the
 // instantiations live in qasr_sep_t{32,64}{,_dbg}.hip so that they compile in parallel).
 #include "qasr_sep_impl.h"
+#include "qasr_sep2_impl.h"
 
 namespace qasr {
 
@@ -10,6 +11,13 @@ extern template void launch_sep_inst<32, false>(hipStream_t, const SepP&);
 extern template void launch_sep_inst<32, true>(hipStream_t, const SepP&);
 extern template void launch_sep_inst<64, false>(hipStream_t, const SepP&);
 extern template void launch_sep_inst<64, true>(hipStream_t, const SepP&);
+extern template int launch_sep2_inst<32, false>(hipStream_t, const SepP&);
+extern template int launch_sep2_inst<32, true>(hipStream_t, const SepP&);
+extern template int launch_sep2_inst<64, false>(hipStream_t, const SepP&);
+extern template int launch_sep2_inst<64, true>(hipStream_t, const SepP&);
+
+// k_sep2 takes the stride-1 separable layers it is built for (sep2_shape_ok) unless the engine was told to stay on k_sep
+bool sep2_takes(const SepP& p) { return p.gen == 2 && sep2_shape_ok(p); }
 
 bool sep_supported(int K, int dilation) {
   if (dilation == 2) return K == 87 || K == 15;
@@ -19,6 +27,11 @@ bool sep_supported(int K, int dilation) {
 // template arguments of the k_sep instantiation launch_sep picks for `p` (as rocprofv3 prints them)
 void sep_kernel_label(const SepP& p, char* buf, size_t cap) {
   const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
+  if (sep2_takes(p)) {
+    snprintf(buf, cap, "k_sep2<%d, %d, %s, %d>", p.K, (p.e.flags & QASR_F_RESADD) ? EP2_RESADD1 : EP2_PLAIN, dbg ? "true" : "false",
+             p.tile == 64 ? 64 : 32);
+    return;
+  }
   snprintf(buf, cap, "k_sep<%d, %d, %d, %s, %d>", p.K, p.K > 0 ? p.dilation : 1, sep_epilogue_class(p), dbg ? "true" : "false",
            sep_tile_for(p));
 }
@@ -30,8 +43,13 @@ int sep_tile_for(const SepP& p) {
   return (p.tile == 64 && (p.dense_k > 1 || sep_epilogue_class(p) != EP_GENERIC)) ? 64 : 32;
 }
 
-void launch_sep(hipStream_t s, const SepP& p) {
+int launch_sep(hipStream_t s, const SepP& p) {
   const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
+  if (sep2_takes(p)) {
+    if (p.tile == 64) return dbg ? launch_sep2_inst<64, true>(s, p) : launch_sep2_inst<64, false>(s, p);
+    return dbg ? launch_sep2_inst<32, true>(s, p) : launch_sep2_inst<32, false>(s, p);
+  }
+  if (!sep_supported(p.K, p.K > 0 ? p.dilation : 1)) return QASR_ERR_UNSUPPORTED;
   if (sep_tile_for(p) == 64) {
     if (dbg) launch_sep_inst<64, true>(s, p);
     else launch_sep_inst<64, false>(s, p);
@@ -39,6 +57,7 @@ void launch_sep(hipStream_t s, const SepP& p) {
     if (dbg) launch_sep_inst<32, true>(s, p);
     else launch_sep_inst<32, false>(s, p);
   }
+  return QASR_OK;
 }
 
 }  // namespace qasr

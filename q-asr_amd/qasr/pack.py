@@ -22,13 +22,14 @@ import torch
 from . import quant_math as Q
 from .topology import ModelCfg, conv_plan
 
-MAGIC, VERSION = 0x52534151, 5
+MAGIC, VERSION = 0x52534151, 6
 OP_QUANT_IN, OP_DW, OP_PW, OP_DENSE, OP_LOGSOFTMAX, OP_REQUANT = range(6)
-F_RELU, F_MASK_OUT, F_EXACT_Z, F_LOGITS, F_RESADD, F_TAPMAJOR = 1, 2, 4, 8, 16, 32
+F_RELU, F_MASK_OUT, F_EXACT_Z, F_LOGITS, F_RESADD, F_TAPMAJOR, F_WIDE_RQ = 1, 2, 4, 8, 16, 32, 64
 DT_S8, DT_U8, DT_F32, DT_I32 = range(4)
 MAX_PANES, MAX_OUTS = 12, 3
 COUT_ALIGN, CIN_ALIGN = 128, 128
 Z_EXACT_LIMIT = (1 << 22) - 1       # below this z == acc is a theorem
+RQ_NARROW_LIMIT = float(1 << 30)    # |acc * M| below this: the low word of fma(acc, M, 1.5*2^52) is the rounded product
 
 
 def fragment_order(w: np.ndarray) -> np.ndarray:
@@ -110,7 +111,7 @@ class Packer:
         assert bound < 2 ** 31 - 2 ** 24, f'{key}: int32 accumulator could overflow ({bound})'
         if in_unsigned:               # u8 input is fed as (x - 128): fold 128*sum(W) into the bias
             bi = bi + 128 * wi.reshape(w.shape[0], -1).sum(1)
-        return wi, bi, s_b, bound > Z_EXACT_LIMIT
+        return wi, bi, s_b, bound
 
     def _act(self, ai, bits):
         s = Q.sym_scale(bits, self.amin[ai], self.amax[ai]).reshape(1)
@@ -157,8 +158,9 @@ class Packer:
                 cons = self._consume(cur, ai, bits)
                 ai += 1
                 in_unsigned = cons.hi > 127
-                wi, bint, s_b, exact = self._conv_ints(s.key, s.bn_key, cons.s_x, in_unsigned,
+                wi, bint, s_b, bound = self._conv_ints(s.key, s.bn_key, cons.s_x, in_unsigned,
                                                        max(abs(cons.lo), abs(cons.hi)))
+                exact = bound > Z_EXACT_LIMIT
                 dom = cur.domain
                 if not (s.stride == 1 and 2 * s.padding == s.dilation * (s.kernel - 1)):
                     self.domains.append(dict(parent=dom, kernel=s.kernel, stride=s.stride, dilation=s.dilation,
@@ -166,7 +168,7 @@ class Packer:
                     dom = len(self.domains) - 1
                 kind = OP_DW if s.role == 'dw' else (OP_PW if s.kernel == 1 else OP_DENSE)
                 op = dict(kind=kind, flags=F_MASK_OUT | (F_RELU if s.relu_after else 0) | (F_EXACT_Z if exact else 0),
-                          site=s, inp=cons, wi=wi, bint=bint, s_b=s_b, panes=[], in_unsigned=in_unsigned)
+                          site=s, inp=cons, wi=wi, bint=bint, s_b=s_b, panes=[], in_unsigned=in_unsigned, bound=bound)
                 if kind == OP_DENSE and s.stride == 1 and (s.kernel & 1) and 2 * s.padding == s.dilation * (s.kernel - 1):
                     op['flags'] |= F_TAPMAJOR                # runs as taps shifted 1x1 GEMMs on the tile kernel
                 self.ops.append(op)
@@ -185,12 +187,13 @@ class Packer:
                     cons = self._consume(src, ai, bits)
                     ai += 1
                     in_unsigned = cons.hi > 127
-                    wi, bint, s_b, exact = self._conv_ints(s.key, s.bn_key, cons.s_x, in_unsigned,
+                    wi, bint, s_b, bound = self._conv_ints(s.key, s.bn_key, cons.s_x, in_unsigned,
                                                            max(abs(cons.lo), abs(cons.hi)))
+                    exact = bound > Z_EXACT_LIMIT
                     if exact:
                         main_op['flags'] |= F_EXACT_Z
                     main_op['panes'].append(dict(site=s, inp=cons, wi=wi, bint=bint, s_b=s_b,
-                                                 in_unsigned=in_unsigned))
+                                                 in_unsigned=in_unsigned, bound=bound))
                     self.sites.append((cur.op, len(main_op['panes']) - 1))
                 assert len(main_op['panes']) <= MAX_PANES
                 cur = _Value('q', cur.op, main_op['site'].cout, cur.domain, S)
@@ -205,8 +208,8 @@ class Packer:
         cons = self._consume(enc, ai, self.abit)
         ai += 1
         assert ai == len(self.amin), (ai, len(self.amin))
-        wi, bint, s_b, exact = self._conv_ints('decoder.decoder_layers.0', None, cons.s_x, False,
-                                               max(abs(cons.lo), abs(cons.hi)))
+        wi, bint, s_b, _ = self._conv_ints('decoder.decoder_layers.0', None, cons.s_x, False,
+                                           max(abs(cons.lo), abs(cons.hi)))
         ncls = wi.shape[0]
         dsite = type('S', (), dict(key='decoder', cin=enc.channels, cout=ncls, kernel=1, stride=1, dilation=1,
                                    padding=0, groups=1, role='dec'))()
@@ -273,6 +276,19 @@ class Packer:
                 self.tensors[op['out_tensor']]['producer'] = oi
 
     @staticmethod
+    def _wide_requant(op):
+        """True when some |acc * M| of the op may reach 2^30: k_sep2 takes the rounded product from the low mantissa
+        word (exact below 2^31), k_sep clamps in the double domain and takes such ops instead."""
+        b = float(op.get('bound', 0))
+        ms = []
+        if op['flags'] & F_RESADD:
+            ms.append((b, Q.requant_multiplier(op['s_b'], op['S'])))
+            ms += [(float(p['bound']), Q.requant_multiplier(p['s_b'], op['S'])) for p in op['panes']]
+        else:
+            ms += [(b, o['M']) for o in op.get('outs', []) if o['mode'] == 1 and o['M'] is not None]
+        return any(bb * float(_t(m).abs().max()) >= RQ_NARROW_LIMIT for bb, m in ms)
+
+    @staticmethod
     def _nonneg(prod):
         # after ReLU the requantised value is >= 0: fold max(.,0) into the clamp's lower bound
         return bool(prod['flags'] & F_RELU)
@@ -324,6 +340,8 @@ class Packer:
             cout = op['cout'] if site is None else site.cout
             cp = _rup(cout, COUT_ALIGN)
             w_off = bias_off = m_off = sb_off = 0
+            if kind in (OP_DW, OP_PW, OP_DENSE) and self._wide_requant(op):
+                op['flags'] |= F_WIDE_RQ
             if kind in (OP_DW, OP_PW, OP_DENSE):
                 w_off = self._pack_weights(kind, op['wi'], bool(op['flags'] & F_TAPMAJOR))
                 bias_off = self._vec(op['bint'].to(torch.int32), cp, np.int32)

@@ -363,3 +363,65 @@ def test_requant_fast_path_adversarial(eng):
             assert np.array_equal(got.astype(np.int8)[ok], want.astype(np.int64)[ok].astype(np.int8))
         else:
             assert np.array_equal(got, want.astype(np.int64)), (lo, hi, int((got != want).sum()))
+
+
+# ---------------------------------------------------------------------------------- production shape
+GENERATIONS = [dict(gen=2), dict(gen=2, wide_tiles=True), dict(gen=1), dict(gen=1, wide_tiles=True), dict(gen=1, whole_utterance=True)]
+GEN_IDS = ['k_sep2_32', 'k_sep2_64', 'k_sep_32', 'k_sep_64', 'k_utt']
+
+
+def _engine_gen(eng, blob, gen, **kw):
+    """QASR_SEP_GEN is read at engine creation: 1 keeps every separable layer on k_sep, 2 (default) routes the stride-1
+    layers with 256 / 512 input channels to k_sep2."""
+    old = os.environ.get('QASR_SEP_GEN')
+    os.environ['QASR_SEP_GEN'] = str(gen)
+    try:
+        return eng.Engine(blob, 0, **kw)
+    finally:
+        if old is None:
+            del os.environ['QASR_SEP_GEN']
+        else:
+            os.environ['QASR_SEP_GEN'] = old
+
+
+@pytest.fixture(scope='module')
+def oracle_quartznet_t500(golden_dir):
+    """OracleNet on 2 utterances x 500 frames (one full, one ragged) of QuartzNet15x5 w8a8: every accumulator."""
+    d, meta = _load(golden_dir, 'net_quartznet_w8a8')
+    cfg = topology.quartznet15x5()
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    net = O.OracleNet(topology.conv_plan(cfg), cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    x = synth.make_features(2, 64, 500, 3)
+    lens = [500, 437]
+    want = net.forward(x, lens)
+    blob, pm = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    return dict(x=x, lens=lens, want=want, accs=[t['acc'] for t in net.trace], blob=blob, pm=pm, cfg=cfg)
+
+
+@pytest.mark.parametrize('family', GENERATIONS, ids=GEN_IDS)
+def test_quartznet_t500_every_accumulator(eng, oracle_quartznet_t500, family):
+    """The production kernels at the production tile count (T = 500 -> 250 frames = 8 / 4 time tiles per utterance, halos
+    crossing tile borders, a ragged utterance): EVERY conv accumulator of QuartzNet15x5 against the CPU oracle
+    (quant_modules.py:301-305), bit-exact, for both kernel generations, both tile sizes and the whole-utterance kernels."""
+    o = oracle_quartznet_t500
+    fam = dict(family)
+    e = _engine_gen(eng, o['blob'], fam.pop('gen'), debug=True, **fam)
+    logp, tokens, enc_len = e.forward(torch.from_numpy(o['x']).cuda(), torch.tensor(o['lens']))
+    torch.cuda.synchronize()
+    couts = _site_dims(o['cfg'])
+    labels = e.op_labels()
+    if family.get('gen') == 2:
+        assert sum(l.startswith('k_sep2<') for l in labels) >= 70, labels      # the new kernel is what runs
+    else:
+        assert not any(l.startswith('k_sep2<') for l in labels)
+    for i, (op, pane) in enumerate(o['pm']['sites']):
+        want = o['accs'][i]
+        got = e.read_acc(op, pane, couts[i], want.shape[2])
+        assert np.array_equal(got, want), f'conv {i} (op {op}, pane {pane}, {labels[op]})'
+    want = o['want']
+    assert np.array_equal(enc_len.cpu().numpy(), want['enc_len'])
+    for b in range(2):
+        n = int(want['enc_len'][b])
+        assert np.array_equal(tokens.cpu().numpy()[b, :n], want['tokens'][b, :n])
+        np.testing.assert_allclose(logp.cpu().numpy()[b, :n], want['log_probs'][b, :n], rtol=1e-4, atol=5e-5)
+    e.close()
