@@ -203,6 +203,24 @@ __global__ void k_mfma444(long long* out, int* sink, int seed) {
   for (int i = 0; i < 8; ++i) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
   sink[threadIdx.x] = s;
 }
+template <int NC>
+__global__ void k_mfma444_chains(long long* out, int* sink, int seed) {
+  v4i c[NC];
+  for (int i = 0; i < NC; ++i) c[i] = (v4i){0, 0, 0, 0};
+  int a = seed + threadIdx.x, b = seed * 7 + threadIdx.x;
+  long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < LOOPS; ++it) {
+#pragma unroll
+    for (int r = 0; r < 8 / NC; ++r)
+#pragma unroll
+      for (int i = 0; i < NC; ++i) c[i] = __builtin_amdgcn_mfma_i32_4x4x4i8(a, b, c[i], 0, 0, 0);
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) { out[2 * (threadIdx.x >> 6)] = t0; out[2 * (threadIdx.x >> 6) + 1] = t1; }
+  int s = 0;
+  for (int i = 0; i < NC; ++i) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
+  sink[threadIdx.x] = s;
+}
 __global__ void k_mfma32(long long* out, int* sink, int seed) {
   v16i c[4];
   for (int i = 0; i < 4; ++i)
@@ -296,6 +314,21 @@ __global__ void __launch_bounds__(512) k_l2bw(const v4i* __restrict__ w, int n16
   if (acc[0] == 0x12345678) sink[0] = acc[1] + acc[2] + acc[3];
 }
 
+// every work-group streams ITS OWN `bytes` region (16 B per lane), as the depthwise window loads do
+__global__ void __launch_bounds__(512) k_l2bw_own(const v4i* __restrict__ w, int n16_per_thread, long long* out, int* sink) {
+  v4i acc = {0, 0, 0, 0};
+  const v4i* p = w + (size_t)blockIdx.x * n16_per_thread * 512 + threadIdx.x;
+  long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 4
+  for (int i = 0; i < n16_per_thread; ++i) {
+    v4i v = p[(size_t)i * 512];
+    acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3];
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+  if (acc[0] == 0x12345678) sink[0] = acc[1] + acc[2] + acc[3];
+}
+
 template <class K>
 static double run1(K kern, int waves_per_simd, long long* d_out, int* d_sink) {
   long long h[64];
@@ -332,6 +365,9 @@ int main() {
   ROW("requant f64 (per value)", k_rq_f64, 16);
   ROW("requant f32+vote (per value)", k_rq_f32, 16);
   ROW("v_mfma_i32_4x4x4_16b_i8", k_mfma444, 8);
+  ROW("  4x4x4, 1 dependent chain", k_mfma444_chains<1>, 8);
+  ROW("  4x4x4, 2 chains", k_mfma444_chains<2>, 8);
+  ROW("  4x4x4, 4 chains", k_mfma444_chains<4>, 8);
   ROW("v_mfma_i32_32x32x32_i8", k_mfma32, 8);
   ROW("v_mfma_i32_16x16x64_i8", k_mfma16, 8);
   ROW("ds_write_b8 (scatter)", k_lds_b8, 8);
@@ -371,6 +407,19 @@ int main() {
       printf("L2->VGPR, %d x 512-thread WGs each streaming the same 256 KiB (16 B/lane): mean %.0f ticks, max %.0f  -> %.1f B/clk per WG (mean)\n",
              grid, s / grid, mx, bytes / (s / grid));
     }
+  }
+  {
+    const size_t per_wg = 64 * 1024;
+    v4i* w;
+    hipMalloc(&w, per_wg * 256);
+    hipMemset(w, 1, per_wg * 256);
+    std::vector<long long> h(256);
+    for (int rep = 0; rep < 4; ++rep) hipLaunchKernelGGL(k_l2bw_own, dim3(256), dim3(512), 0, 0, w, (int)(per_wg / (512 * 16)), d_out, d_sink);
+    hipMemcpy(h.data(), d_out, 8 * 256, hipMemcpyDeviceToHost);
+    double s = 0, mx = 0;
+    for (int i = 0; i < 256; ++i) { s += h[i]; mx = h[i] > mx ? h[i] : mx; }
+    printf("L2->VGPR, 256 x 512-thread WGs each streaming ITS OWN 64 KiB (16 MiB in all, 4th back-to-back launch): mean %.0f ticks, max %.0f -> %.1f B/clk per WG\n",
+           s / 256, mx, per_wg / (s / 256));
   }
   return 0;
 }

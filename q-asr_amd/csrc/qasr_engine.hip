@@ -333,7 +333,8 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
       return fail(QASR_ERR_BLOB, "op %u malformed", i);
     }
   }
-  if (hipMalloc((void**)&e->dblob, n) != hipSuccess || hipMemcpy(e->dblob, blob, n, hipMemcpyHostToDevice) != hipSuccess) {
+  if (hipMalloc((void**)&e->dblob, n + 256) != hipSuccess ||      // slack: 16-byte granule copies may overrun an array's tail
+      hipMemcpy(e->dblob, blob, n, hipMemcpyHostToDevice) != hipSuccess) {
     delete e;
     return fail(QASR_ERR_HIP, "blob upload failed");
   }

@@ -28,8 +28,8 @@ bool sep_supported(int K, int dilation) {
 void sep_kernel_label(const SepP& p, char* buf, size_t cap) {
   const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
   if (sep2_takes(p)) {
-    snprintf(buf, cap, "k_sep2<%d, %d, %s, %d>", p.K, (p.e.flags & QASR_F_RESADD) ? EP2_RESADD1 : EP2_PLAIN, dbg ? "true" : "false",
-             p.tile == 64 ? 64 : 32);
+    snprintf(buf, cap, "k_sep2<%d, %d, %d, %d, %s, %d>", p.K, p.cin_pad >> 7, (p.e.flags & QASR_F_RESADD) ? p.panes[0].cin_pad >> 7 : 0,
+             (p.e.cout + 255) / 256, dbg ? "true" : "false", p.tile == 64 ? 64 : 32);
     return;
   }
   snprintf(buf, cap, "k_sep<%d, %d, %d, %s, %d>", p.K, p.K > 0 ? p.dilation : 1, sep_epilogue_class(p), dbg ? "true" : "false",

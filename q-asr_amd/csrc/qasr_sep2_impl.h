@@ -4,12 +4,17 @@
 //
 // Same decomposition as k_sep (work-group = 512 threads = one utterance x TT frames x every channel; grid (B, Tp/TT)
 // with the utterance as the fastest index so that all tiles of an utterance share one XCD's L2), rebuilt around what
-// the round-2 micro-benchmarks (profiles/microbench/) showed:
+// the round-2 micro-benchmarks (profiles/microbench/) and phase stamps showed:
 //   * integer / f64 VALU instructions all issue at ~4.3 cycles per wave-instruction and SIMD, so the f64 form
 //     lo32(fma(f64(z), M, 1.5*2^52)) + v_med3_i32 (3 instructions, exact) replaces the 9-instruction float32 fast path
 //     with its ambiguity vote;
-//   * the matrix pipe is the floor (v_mfma_i32_4x4x4 8.3, 32x32x32 32.2 cycles): everything else has to hide
-//     behind it, which needs >= 2 work-groups per CU -> <= 128 VGPRs, <= 80 KiB LDS;
+//   * a CU takes ~50 B/clk from L2 and one work-group asks for ~0.5 MB (256 KiB of 1x1 weights, the window, the taps):
+//     the texture path is the busiest unit, so nothing is fetched twice - the tap rows of a chunk are staged ONCE
+//     through LDS (k_sep: every lane fetched its own pre-shifted copy, 4x the bytes) - and requests are issued in the
+//     order the math needs them (window, taps, then the weight slab);
+//   * every global operand is requested >= 1 k cycles before its use: the whole weight slab of the next GEMM sits in
+//     registers (re-requested group by group as soon as a group has been multiplied), per-channel parameters of the
+//     next pass travel during the current one;
 //   * the depthwise stage read one LDS dword per 4x4x4 MFMA (LDS ~100 % busy): the 4 columns of a block now take
 //     frames S = TT/4 apart, so a lane reads ONE contiguous, aligned run of its window row (ds_read_b64 / b128) and
 //     every dword feeds the TT/16 accumulation chains;
@@ -18,21 +23,29 @@
 //     the residual operand is a plain 16-byte copy of the [channel][frame] tensor for the same reason;
 //   * the epilogue stays in the MFMA C layout: requant, pack, two v_permlane32_swap to give each lane 16 consecutive
 //     frames, one 16-byte store per lane and consumer - no LDS staging tile, no wave barriers;
-//   * 1x1 weights stream through two register buffers of 4 K steps (the next group travels during the current
-//     group's MFMAs) instead of a 64-VGPR slab held across the depthwise stage.
+//   * the K depth of both GEMMs is a template parameter (groups of 128 input channels): with run-time group guards the
+//     compiler renamed accumulators and weight buffers at every join, spilled fresh weight loads behind
+//     s_waitcnt vmcnt(0) and serialised the LDS reads.
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <type_traits>
 
 #include "qasr_device.h"
 
 namespace qasr {
 
 typedef int v2i __attribute__((ext_vector_type(2)));
+// LDS pointers stay in address space 3 (32-bit): derived through generic pointers the offsets were computed with 64-bit
+// multiply-adds whose unused upper halves dragged unrelated pending loads into every address (s_waitcnt vmcnt(0))
+typedef unsigned char __attribute__((address_space(3))) lds_u8;
+typedef unsigned __attribute__((address_space(3))) lds_u32;
+typedef v2i __attribute__((address_space(3))) lds_v2i;
+typedef v4i __attribute__((address_space(3))) lds_v4i;
 
 #define SEP2_NT 512
 #ifndef SEP2_WPE
-#define SEP2_WPE 4                      /* waves per SIMD the register budget is sized for (2 work-groups per CU) */
+#define SEP2_WPE 2                      /* waves per SIMD the register budget is sized for: 2 = one work-group per CU, 256 VGPRs */
 #endif
 #define SEP2_CH 256                     /* channels per staged window chunk */
 
@@ -50,14 +63,18 @@ struct Sep2Geo {
   static constexpr int NE = OFF + NU + NS - 1;           // dwords of the lane stream
   static constexpr int NRD = (4 * NE + S - 1) / S;       // S-byte LDS reads per lane and group
   static constexpr int WLEN = TT + 2 * HALO;             // staged bytes per window row
-  static constexpr int WP = WLEN;                        // LDS row pitch
+  // LDS row pitch: the lanes of one LDS access group read S-byte runs of 4 (b128) / 8 (b64) different rows; an odd
+  // multiple of 4 S bytes puts those rows on disjoint banks (a power-of-two pitch made every read 4-way conflicted)
+  static constexpr int WP = ((WLEN + 4 * S - 1) / (4 * S) | 1) * (4 * S);
   static constexpr int NPG = WLEN / 16;                  // 16-B granules per row
-  static constexpr int NPT = (SEP2_CH * NPG + SEP2_NT - 1) / SEP2_NT;   // granules per thread and chunk
+  static constexpr int NPT = (SEP2_CH * NPG + SEP2_NT - 1) / SEP2_NT;   // window granules per thread and chunk
   static constexpr int KP4 = (K + 3) / 4;
   static constexpr int KS = 4 * KP4 + 32;                // row pitch of the zero-margined tap array (pack.py)
-  static constexpr int NR = (NS + 1 + 3) / 4 * 4;        // tap dwords fetched per lane (whole 16-B loads)
-  static_assert(3 * S + (A0 & ~(S - 1)) + NRD * S <= WP, "lane stream leaves the window row");
-  static_assert(8 + MS - 3 >= 0 && 4 * (((8 + MS) >> 2) + NR) <= KS, "tap stream leaves the tap row");
+  static constexpr int TAPB = SEP2_CH * KS;              // tap bytes of a chunk (256 KS is a multiple of 16)
+  static constexpr int NTT = (TAPB / 16 + SEP2_NT - 1) / SEP2_NT;       // tap granules per thread and chunk
+  static_assert(3 * S + (A0 & ~(S - 1)) + NRD * S <= WLEN && WLEN <= WP, "lane stream leaves the window row");
+  static_assert(8 + MS - 3 >= 0 && 8 + MS + 4 * (NS + 1) <= KS, "tap stream leaves the tap row");
+  static_assert(TAPB % 16 == 0, "tap chunk is not 16-byte granular");
 };
 
 // rint(z * M) for |z * M| < 2^31 (the packer routes ops that cannot promise this to k_sep): one fp64 fma rounds
@@ -75,6 +92,7 @@ __device__ __forceinline__ unsigned pack4b(int a, int b, int c, int d) {
   const unsigned hi = __builtin_amdgcn_perm((unsigned)d, (unsigned)c, 0x04000c0cu);    // [0, 0, c0, d0]
   return lo | hi;
 }
+
 // ---- 1x1 GEMM over [channel][32-frame] LDS images --------------------------------------------------------------
 // A fragment of K step ks for lane (r = lane & 31, h = lane >> 5): channels 32 ks + 16 h + {0..15} of frame r.  Two
 // transposing reads: the 16 lanes of a group supply the 8 rows x 16 bytes of a block (lane 2q+p: row q, bytes 8p..8p+7)
@@ -82,64 +100,78 @@ __device__ __forceinline__ unsigned pack4b(int a, int b, int c, int d) {
 __device__ __forceinline__ int sep2_a_lane_off(int lane) {
   return (16 * (lane >> 5) + ((lane & 15) >> 1)) * 32 + 16 * ((lane >> 4) & 1) + 8 * (lane & 1);
 }
-__device__ __forceinline__ v4i sep2_a_frag(const unsigned char* img_lane, int ks) {
-  typedef v2i __attribute__((address_space(3))) * lds_v2i;
-  const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i)(img_lane + ks * 1024));
-  const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i)(img_lane + ks * 1024 + 256));
+__device__ __forceinline__ v4i sep2_a_frag(const lds_u8* img_lane, int ks) {
+  const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(img_lane + ks * 1024));
+  const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(img_lane + ks * 1024 + 256));
   return (v4i){lo[0], lo[1], hi[0], hi[1]};
 }
-__device__ __forceinline__ void sep2_load_wg(v4i (&wb)[4], const v4i* __restrict__ wp) {
+__device__ __forceinline__ void sep2_load_wg(v4i* wb, const v4i* __restrict__ wp) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) wb[i] = wp[64 * i];          // consecutive K steps are 1 KiB apart (fragment order)
 }
-template <int MT>
-__device__ __forceinline__ void sep2_mma_group(v16i (&acc)[MT], const v4i (&wb)[4], const unsigned char* img_lane, int mt_stride,
-                                               int g) {
-  // two K steps at a time: 8 MT registers of A fragments in flight instead of 16 MT
+// One 1x1 GEMM of N groups of 4 K steps on the register-resident weight slab wf (group g in wf[4g .. 4g+3]).  As soon
+// as group g has been multiplied its registers are re-requested: from r0 + 256 g for g < N0, else from r1 + 256 g
+// (nullptr: nothing) - the same group of the GEMM that runs next on these registers.  A fragments are double-buffered
+// two K steps at a time so that the LDS latency of the next pair hides behind the current pair's MFMAs.
+template <int MT, int N, int N0>
+__device__ __forceinline__ void sep2_gemm(v16i (&acc)[MT], v4i (&wf)[16], const lds_u8* img_lane, int mt_stride,
+                                          const v4i* __restrict__ r0, const v4i* __restrict__ r1) {
+  v4i a[2][MT][2];
 #pragma unroll
-  for (int i2 = 0; i2 < 4; i2 += 2) {
-    v4i a[MT][2];
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int i = 0; i < 2; ++i) a[0][mt][i] = sep2_a_frag(img_lane + mt * mt_stride, i);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[mt][i] = sep2_a_frag(img_lane + mt * mt_stride, 4 * g + i2 + i);
+  for (int q = 0; q < 2 * N; ++q) {                          // pair of K steps; group g = q >> 1
+    if (q + 1 < 2 * N) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[(q + 1) & 1][mt][i] = sep2_a_frag(img_lane + mt * mt_stride, 2 * (q + 1) + i);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mt][i], wb[i2 + i], acc[mt], 0, 0, 0);
-  }
-}
-// n (even) groups of 4 K steps; wb0 holds group 0 on entry and the first group of `next` (the GEMM that follows; any
-// valid fragment pointer when nothing follows) on exit.  The next group always travels while the current one is on the
-// matrix cores.  One rolled pair loop, no guards: unrolled with per-group conditions the accumulators and both buffers
-// were renamed at every join and fresh weight loads got spilled behind s_waitcnt vmcnt(0).
-template <int MT>
-__device__ __forceinline__ void sep2_gemm(v16i (&acc)[MT], v4i (&wb0)[4], v4i (&wb1)[4], const unsigned char* img_lane, int mt_stride,
-                                          const v4i* __restrict__ wp, int n, const v4i* __restrict__ next) {
-#pragma unroll 1
-  for (int i = 0; i < n; i += 2) {
-    sep2_load_wg(wb1, wp + 256 * (i + 1));
-    sep2_mma_group<MT>(acc, wb0, img_lane + 4096 * i, mt_stride, 0);
-    sep2_load_wg(wb0, i + 2 < n ? wp + 256 * (i + 2) : next);
-    sep2_mma_group<MT>(acc, wb1, img_lane + 4096 * (i + 1), mt_stride, 0);
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q & 1][mt][i], wf[2 * q + i], acc[mt], 0, 0, 0);
+    if (q & 1) {
+      const int g = q >> 1;
+      if (g < N0) {
+        if (r0) sep2_load_wg(&wf[4 * g], r0 + 256 * g);
+      } else {
+        if (r1) sep2_load_wg(&wf[4 * g], r1 + 256 * g);
+      }
+    }
   }
 }
 
-enum { EP2_PLAIN = 1, EP2_RESADD1 = 2 };
+// per-lane (= per output channel, MFMA C layout: channel = lane & 31) parameters of one 256-channel pass
+struct Sep2PassP {
+  int bias, pbias;
+  double Mo[QASR_MAX_OUTS];                                  // PLAIN: the consumers' per-channel multipliers
+  double Mm, Mp;                                             // RESADD: main / residual multipliers towards res_act
+  float sbm, sbp;                                            // EXACT_Z: conv output scales
+};
 
-template <int K, int EP, bool DBG, int TT>
+// K taps, NG groups of 128 input channels (cin_pad = 128 NG), NGP groups of the residual 1x1 conv (0: no res_act),
+// NP passes of 256 output channels - all compile-time: the whole kernel is straight-line code, which is what lets the
+// compiler count its s_waitcnt vmcnt(N) exactly instead of draining every prefetch at each join
+template <int K, int NG, int NGP, int NP, bool DBG, int TT>
 __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   using G = Sep2Geo<K, TT>;
+  constexpr bool RES = NGP > 0;
   constexpr int MT = TT / 32;
   constexpr int NU = G::NU, S = G::S, NS = G::NS;
+  constexpr int CIN_PAD = 128 * NG, PCIN_PAD = 128 * NGP;
+  constexpr int NCHUNK = (CIN_PAD + SEP2_CH - 1) / SEP2_CH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const EpiP& e = p.e;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x, t0 = blockIdx.y * TT;
-  const int cin = p.cin, cin_pad = p.cin_pad;
-  unsigned char* const Xd = smem;                            // [MT][cin_pad][32]  A image of the 1x1 conv
-  unsigned char* const Ws = smem + TT * cin_pad;             // [<= 256][WP] window chunk; later the residual A image
+  lds_u8* const Xd = (lds_u8*)smem;                          // [MT][CIN_PAD][32]  A image of the 1x1 conv
+  lds_u8* const Tl = Xd + TT * CIN_PAD;                      // [256][KS] tap rows of the current chunk
+  lds_u8* const Ws = Tl + G::TAPB + 64;                      // [<= 256][WP] window chunk; later the residual A image
 
   const unsigned flags = e.flags;
   const int eT = e.T, eTp = e.Tp, ecout = e.cout, n_outs = e.n_outs;
@@ -148,202 +180,254 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   const int dlim = min(len_b, eT);                           // the 1x1 conv's MaskedConv1d masks its input
   const bool f_relu = flags & QASR_F_RELU;
   const bool f_exact = flags & QASR_F_EXACT_Z;
-  const int cout_pad = (ecout + 127) / 128 * 128;
-  const int ng = cin_pad >> 7;                               // groups of 4 K steps
   const int dw_lo = p.dw_lo, dw_hi = p.dw_hi;
   const bool stamp = p.prof && blockIdx.x == 0 && blockIdx.y == 1 && tid == 0;
   int nst = 0;
 #define STAMP2() do { if (stamp && nst < 31) p.prof[nst++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   STAMP2();
 
-  // ------------------------------------------------------------------------------------------ window fetch / commit
+  // Shapes are exact (sep2_shape_ok): cin == CIN_PAD, cout == 256 NP, residual cin == PCIN_PAD - no row / channel guards.
+  // ------------------------------------------------------------------------------------------ global requests
+  // A CU's texture path takes one 64-lane x 16-B request per 16 cycles and a work-group needs ~350 of them (0.36 MB):
+  // a wave that issues its share in one burst sits in that queue for thousands of cycles (phase stamps).  Only what
+  // the first depthwise chunk needs is requested up front; everything else (next chunk's window and taps, the
+  // residual operand, the weight slab of GEMM pass 0) is a list of single requests issued a few at a time between
+  // the depthwise math (pf<CH>(lo, hi)).
   const unsigned flip = p.x_unsigned ? 0x80808080u : 0u;
-  v4i pc[G::NPT];
-  auto fetch = [&](int c0) {                                 // global -> registers (coalesced 16-B granules)
-    const int nch = min(SEP2_CH, cin - c0);
-#pragma unroll
-    for (int i = 0; i < G::NPT; ++i) {
-      const int pi = tid + SEP2_NT * i;
-      const int row = pi / G::NPG, col = pi - row * G::NPG;
-      const int t = t0 - G::HALO + 16 * col;                 // a granule lies entirely inside or outside [0, Tp)
-      pc[i] = (v4i){0, 0, 0, 0};
-      if (row < nch && t >= 0 && t < eTp) pc[i] = *(const v4i*)(p.x + ((size_t)b * cin + c0 + row) * eTp + t);
+  constexpr int NRT = RES ? (TT * PCIN_PAD / 16) / SEP2_NT : 0;
+  v4i pc[G::NPT], pt[G::NTT], rr[NRT > 0 ? NRT : 1], wf[16];
+  const int co_l = 32 * wave + (lane & 31);                  // row inside a 256-channel pass
+  const v4i* const w0 = w_frag(p.w, CIN_PAD, co_l, 0);
+  auto ld_win = [&](int c0, int i) {                         // window granule i of this thread (coalesced 16-B granules)
+    const int pi = tid + SEP2_NT * i;
+    const int row = pi / G::NPG, col = pi - row * G::NPG;
+    const int t = t0 - G::HALO + 16 * col;                   // a granule lies entirely inside or outside [0, Tp)
+    // unconditional load from a clamped address (commit() zeroes what lies outside): a load under a branch with a
+    // zero-initialised destination is waited for on the spot
+    pc[i] = *(const v4i*)(p.x + ((size_t)b * CIN_PAD + c0 + min(row, SEP2_CH - 1)) * eTp + min(max(t, 0), eTp - 16));
+  };
+  auto ld_tap = [&](int c0, int i) {                         // the chunk's zero-margined tap rows, ONCE per work-group
+    pt[i] = *(const v4i*)((const unsigned char*)p.wdw2 + (size_t)c0 * G::KS + 16 * min(tid + SEP2_NT * i, G::TAPB / 16 - 1));
+  };
+  auto ld_res = [&](int i) {                                 // residual operand granule: channel gi / (TT/16), 16 frames
+    if constexpr (RES) {
+      const int gi = tid + SEP2_NT * i;
+      const int c = gi / (TT / 16), q = gi - c * (TT / 16);
+      rr[i] = *(const v4i*)(p.panes[0].x + ((size_t)b * PCIN_PAD + c) * eTp + t0 + 16 * q);
     }
   };
-  auto commit = [&](int c0) {                                // registers -> LDS window
-    const int nch = min(SEP2_CH, cin - c0);
+  // request list of depthwise chunk CH: [window + taps of chunk CH+1] [residual operand, last chunk] [weight slab, chunk 0]
+  auto pf = [&](auto chc, int lo, int hi) {
+    constexpr int CH = decltype(chc)::value;
+    constexpr int n_win = CH + 1 < NCHUNK ? G::NPT : 0, n_tap = CH + 1 < NCHUNK ? G::NTT : 0;
+    constexpr int n_res = CH + 1 == NCHUNK ? NRT : 0, n_slab = CH == 0 ? 4 * NG : 0;
+#pragma unroll
+    for (int i = lo; i < hi; ++i) {
+      if (i < n_win) ld_win(SEP2_CH * (CH + 1), i);
+      else if (i < n_win + n_tap) ld_tap(SEP2_CH * (CH + 1), i - n_win);
+      else if (i < n_win + n_tap + n_res) ld_res(i - n_win - n_tap);
+      else if (i < n_win + n_tap + n_res + n_slab) wf[i - n_win - n_tap - n_res] = w0[64 * (i - n_win - n_tap - n_res)];
+    }
+  };
+  auto commit = [&](int c0) {                                // registers -> LDS
 #pragma unroll
     for (int i = 0; i < G::NPT; ++i) {
       const int pi = tid + SEP2_NT * i;
       const int row = pi / G::NPG, col = pi - row * G::NPG;
-      if (row < nch) {
+      if (row < SEP2_CH) {
+        const int t = t0 - G::HALO + 16 * col;
+        const unsigned keep = (t >= 0 && t < eTp) ? 0xffffffffu : 0u;      // conv zero padding beyond the tensor
         v4i v = pc[i];
-        v[0] ^= flip; v[1] ^= flip; v[2] ^= flip; v[3] ^= flip;
-        *(v4i*)(Ws + row * G::WP + 16 * col) = v;
+        v[0] = (v[0] & keep) ^ flip; v[1] = (v[1] & keep) ^ flip; v[2] = (v[2] & keep) ^ flip; v[3] = (v[3] & keep) ^ flip;
+        *(lds_v4i*)(Ws + row * G::WP + 16 * col) = v;
       }
     }
+#pragma unroll
+    for (int i = 0; i < G::NTT; ++i) {
+      const int gi = tid + SEP2_NT * i;
+      if (16 * gi < G::TAPB) *(lds_v4i*)(Tl + 16 * gi) = pt[i];
+    }
   };
-  fetch(0);
+#pragma unroll
+  for (int i = 0; i < G::NPT; ++i) ld_win(0, i);
+#pragma unroll
+  for (int i = 0; i < G::NTT; ++i) ld_tap(0, i);
+  STAMP2();                                                  // requests of chunk 0 issued
 
-  // first weight group of GEMM pass 0 (consumed after the depthwise stage, which hides its latency)
-  const int co_l = 32 * wave + (lane & 31);                  // row inside a 256-channel pass
-  v4i wb0[4], wb1[4];
-  sep2_load_wg(wb0, w_frag(p.w, cin_pad, co_l < cout_pad ? co_l : 0, 0));
-  __builtin_amdgcn_sched_barrier(0);
+  // per-group depthwise parameters of this lane's channels and the per-lane parameters of every GEMM pass: a handful
+  // of registers, requested right behind chunk 0
+  const int cb = lane >> 2, jl = lane & 3;
+  int dbias[2 * NCHUNK];
+  double dM[2 * NCHUNK];
+#pragma unroll
+  for (int gi = 0; gi < 2 * NCHUNK; ++gi) {
+    const int c = SEP2_CH * (gi >> 1) + 32 * wave + 16 * (gi & 1) + cb;
+    dbias[gi] = p.bias_dw[c];
+    dM[gi] = p.m_dw[c];
+  }
+  Sep2PassP pps[NP];
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int cor = 256 * ps + co_l;
+    Sep2PassP& q = pps[ps];
+    q.bias = p.bias[cor];
+    if constexpr (RES) {
+      q.pbias = p.panes[0].bias[cor];
+      q.Mm = e.m_main[cor];
+      q.Mp = p.panes[0].m[cor];
+      q.sbp = f_exact ? p.panes[0].sb[cor] : 1.0f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < QASR_MAX_OUTS; ++j) q.Mo[j] = j < n_outs ? e.outs[j].mtab[cor] : 0.0;
+    }
+    q.sbm = f_exact ? e.sb[cor] : 1.0f;
+  }
 
   // ------------------------------------------------------------------------------------------ depthwise stage
   // v_mfma_i32_4x4x4_16B_i8: 16 independent 4x4x4 products, block = channel.  A[i][k] = w[m0 + k - i] (lane i's own
-  // pre-shifted tap stream), B[k][j] = win[S j + D + m0 + k] (lane j's window run), so the block accumulates
+  // shifted tap stream), B[k][j] = win[S j + D + m0 + k] (lane j's window run), so the block accumulates
   // out[S j + 4 u + i] over taps m0 - i .. m0 - i + 3 for chain u when B is taken 4 u bytes further on; m0 advances
   // by 4 per step.  Lane l: channel l >> 2, row / column l & 3; register v of chain u = frame S (l & 3) + 4 u + v.
   const bool full_in = t0 + TT <= dlim;                      // no masked frame in this tile (uniform)
-  v4i rr[(TT * 512 / 16 + SEP2_NT - 1) / SEP2_NT];           // residual operand granules in flight (EP2_RESADD1)
-  constexpr int NRT = (TT * 512 / 16 + SEP2_NT - 1) / SEP2_NT;
-  auto fetch_res = [&]() {
-    const PaneP& pn = p.panes[0];
+  constexpr int e0base = 8 + G::MS;                          // the lane's tap stream starts at byte e0base - jl of its row
+  const int e0 = e0base - jl, tq = e0 >> 2, tsh = e0 & 3;
+  struct DwIn {                                              // LDS operands of one group of 16 channels
+    unsigned raw[NS + 1];                                    // the lane's tap dwords (whole words, funnel-shifted later)
+    unsigned xs[G::NRD * (S / 4)];                           // the lane's window run: every dword feeds the NU chains
+  };
+  auto dw_read = [&](DwIn& in, int g) {
+    const int row = 32 * wave + 16 * g + cb;
+    const lds_u32* tr = (const lds_u32*)(Tl + row * G::KS + 4 * tq);
 #pragma unroll
-    for (int i = 0; i < NRT; ++i) {
-      const int gi = tid + SEP2_NT * i;                      // granule: channel gi / (TT/16), 16 frames
-      const int c = gi / (TT / 16), q = gi - c * (TT / 16);
-      rr[i] = (v4i){0, 0, 0, 0};
-      if (c < pn.cin) rr[i] = *(const v4i*)(pn.x + ((size_t)b * pn.cin + c) * eTp + t0 + 16 * q);
+    for (int i = 0; i <= NS; ++i) in.raw[i] = tr[i];
+    const lds_u8* wr = Ws + row * G::WP + S * jl + (G::A0 & ~(S - 1));
+#pragma unroll
+    for (int i = 0; i < G::NRD; ++i) {
+      if constexpr (S == 16) {
+        const v4i v = *(const lds_v4i*)(wr + 16 * i);
+        in.xs[4 * i] = v[0]; in.xs[4 * i + 1] = v[1]; in.xs[4 * i + 2] = v[2]; in.xs[4 * i + 3] = v[3];
+      } else {
+        const v2i v = *(const lds_v2i*)(wr + 8 * i);
+        in.xs[2 * i] = v[0]; in.xs[2 * i + 1] = v[1];
+      }
     }
   };
-  for (int c0 = 0; c0 < cin; c0 += SEP2_CH) {
-    const int nch = min(SEP2_CH, cin - c0);
-    const int cb = lane >> 2, jl = lane & 3;
-    constexpr int e0base = 8 + G::MS;                        // the lane's tap stream starts at byte e0base - jl of its row
-    const int e0 = e0base - jl, tq = e0 >> 2, tsh = e0 & 3;
-    if (c0) __syncthreads();                                 // previous chunk's window fully consumed
+  // the math of one group; `pf3(k)` issues the k-th third of the group's share of the request list
+  auto dw_math = [&](const DwIn& in, int c0, int g, int bias, double Mg, auto&& pf3) {
+    const int c = c0 + 32 * wave + 16 * g + cb;
+    unsigned tw[NS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) tw[st] = __builtin_amdgcn_alignbyte(in.raw[st + 1], in.raw[st], tsh);
+    v4i acc[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) acc[u] = (v4i){bias, bias, bias, bias};
+    pf3(0);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      if (st == NS / 2) pf3(1);
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+        acc[u] = __builtin_amdgcn_mfma_i32_4x4x4i8((int)tw[st], (int)in.xs[G::OFF + u + st], acc[u], 0, 0, 0);
+    }
+    pf3(2);
+    if (DBG && p.dw_acc_dbg) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int f = S * jl + 4 * u + v;
+          if (t0 + f < eT) p.dw_acc_dbg[((size_t)b * CIN_PAD + c) * eTp + t0 + f] = acc[u][v];
+        }
+    }
+    if (!full_in) {                                          // masked frames (t >= len): accumulator 0 requantises to 0
+      int dl = dlim - t0 - S * jl;                           // (dw_lo <= 0 <= dw_hi); kept out of the loop-invariant code
+      asm volatile("" : "+v"(dl));
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (4 * u + v >= dl) acc[u][v] = 0;
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int f = S * jl + 4 * u;                          // first of this dword's 4 frames
+      const unsigned w = pack4b(rq_clamp(acc[u][0], Mg, dw_lo, dw_hi), rq_clamp(acc[u][1], Mg, dw_lo, dw_hi),
+                                rq_clamp(acc[u][2], Mg, dw_lo, dw_hi), rq_clamp(acc[u][3], Mg, dw_lo, dw_hi));
+      *(lds_u32*)(Xd + (f >> 5) * (CIN_PAD * 32) + c * 32 + (f & 31)) = w;
+    }
+  };
+
+  auto chunk = [&](auto chc) {
+    constexpr int CH = decltype(chc)::value;
+    constexpr int c0 = SEP2_CH * CH;
+    constexpr int NPF = (CH + 1 < NCHUNK ? G::NPT + G::NTT : 0) + (CH + 1 == NCHUNK ? NRT : 0) + (CH == 0 ? 4 * NG : 0);
+    constexpr int Q = (NPF + 5) / 6;                         // six issue points per chunk
+    if (CH) __syncthreads();                                 // previous chunk's window and taps fully consumed
+    if (stamp) {                                             // diagnostics: when did this wave's window / taps land?
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP2();
+    }
     commit(c0);
-    __syncthreads();
-    const bool last = c0 + SEP2_CH >= cin;
-    if (!last) fetch(c0 + SEP2_CH);                          // next chunk's window travels during this chunk's math
-    if (EP == EP2_RESADD1 && last) fetch_res();
     STAMP2();
-#pragma unroll 1
-    for (int g = 0; g < 2; ++g) {
-      if (32 * wave + 16 * g >= nch) break;                  // wave-uniform: group entirely beyond the chunk
-      const int row = 32 * wave + 16 * g + cb;
-      const bool row_ok = row < nch;
-      const int rowc = min(row, nch - 1);
-      const int c = c0 + rowc;
-      // taps: whole dwords by wide loads (rows are 4-byte aligned), funnel-shifted into place
-      unsigned tw[NS];
-      {
-        v4i raw[G::NR / 4];
-        const v4i* tp = (const v4i*)((const unsigned char*)p.wdw2 + (size_t)c * G::KS + 4 * tq);
+    __syncthreads();
+    if (CH == 0) {
+      // every load issued so far has landed (commit waited for the window); re-define the early per-lane parameters so
+      // that their later uses do not wait for the requests issued from here on
 #pragma unroll
-        for (int i = 0; i < G::NR / 4; ++i) raw[i] = tp[i];
-#pragma unroll
-        for (int st = 0; st < NS; ++st)
-          tw[st] = __builtin_amdgcn_alignbyte((unsigned)raw[(st + 1) >> 2][(st + 1) & 3], (unsigned)raw[st >> 2][st & 3], tsh);
-      }
-      const int biasg = p.bias_dw[c];
-      const double Mg = p.m_dw[c];
-      // the lane's window run: S-byte aligned reads, every dword feeds the NU chains
-      unsigned xs[G::NRD * (S / 4)];
-      {
-        const unsigned char* wr = Ws + rowc * G::WP + S * jl + (G::A0 & ~(S - 1));
-#pragma unroll
-        for (int i = 0; i < G::NRD; ++i) {
-          if constexpr (S == 16) {
-            const v4i v = *(const v4i*)(wr + 16 * i);
-            xs[4 * i] = v[0]; xs[4 * i + 1] = v[1]; xs[4 * i + 2] = v[2]; xs[4 * i + 3] = v[3];
-          } else {
-            const v2i v = *(const v2i*)(wr + 8 * i);
-            xs[2 * i] = v[0]; xs[2 * i + 1] = v[1];
-          }
-        }
-      }
-      v4i acc[NU];
-#pragma unroll
-      for (int u = 0; u < NU; ++u) acc[u] = (v4i){biasg, biasg, biasg, biasg};
-#pragma unroll
-      for (int st = 0; st < NS; ++st)
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-          acc[u] = __builtin_amdgcn_mfma_i32_4x4x4i8((int)tw[st], (int)xs[G::OFF + u + st], acc[u], 0, 0, 0);
-      if (DBG && p.dw_acc_dbg && row_ok) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int f = S * jl + 4 * u + v;
-            if (t0 + f < eT) p.dw_acc_dbg[((size_t)b * cin + c) * eTp + t0 + f] = acc[u][v];
-          }
-      }
-      if (!full_in) {                                        // masked frames (t >= len): accumulator 0 requantises to 0
-        int dl = dlim - t0 - S * jl;                         // (dw_lo <= 0 <= dw_hi); kept out of the loop-invariant code
-        asm volatile("" : "+v"(dl));
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-          for (int v = 0; v < 4; ++v)
-            if (4 * u + v >= dl) acc[u][v] = 0;
-      }
-      if (row_ok) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-          const int f = S * jl + 4 * u;                      // first of this dword's 4 frames
-          const unsigned w = pack4b(rq_clamp(acc[u][0], Mg, dw_lo, dw_hi), rq_clamp(acc[u][1], Mg, dw_lo, dw_hi),
-                                    rq_clamp(acc[u][2], Mg, dw_lo, dw_hi), rq_clamp(acc[u][3], Mg, dw_lo, dw_hi));
-          *(unsigned*)(Xd + (f >> 5) * (cin_pad * 32) + c * 32 + (f & 31)) = w;
-        }
-      }
+      for (int gi = 0; gi < 2 * NCHUNK; ++gi) asm volatile("" : "+v"(dbias[gi]), "+v"(dM[gi]));
     }
     STAMP2();
-  }
+    DwIn inA, inB;
+    dw_read(inA, 0);
+    dw_read(inB, 1);
+    dw_math(inA, c0, 0, dbias[2 * CH], dM[2 * CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
+    dw_math(inB, c0, 1, dbias[2 * CH + 1], dM[2 * CH + 1], [&](int k) { pf(chc, Q * (3 + k), Q * (4 + k)); });
+    STAMP2();
+  };
+  chunk(std::integral_constant<int, 0>{});
+  if constexpr (NCHUNK > 1) chunk(std::integral_constant<int, 1>{});
+  static_assert(NCHUNK <= 2, "more than 512 input channels");
   __syncthreads();                                           // Xd complete, window dead
-  if (EP == EP2_RESADD1) {                                   // residual A image [cin_r_pad][32] per 32-frame tile
-    const PaneP& pn = p.panes[0];
-    const unsigned rflip = pn.x_unsigned ? 0x80808080u : 0u;
+  if constexpr (RES) {                                       // residual A image [PCIN_PAD][32] per 32-frame tile
+    const unsigned rflip = p.panes[0].x_unsigned ? 0x80808080u : 0u;
 #pragma unroll
     for (int i = 0; i < NRT; ++i) {
       const int gi = tid + SEP2_NT * i;
       const int c = gi / (TT / 16), q = gi - c * (TT / 16);
-      if (c < pn.cin) {
-        v4i v = rr[i];
-        v[0] ^= rflip; v[1] ^= rflip; v[2] ^= rflip; v[3] ^= rflip;
-        *(v4i*)(Ws + (q >> 1) * (pn.cin_pad * 32) + c * 32 + 16 * (q & 1)) = v;
-      }
+      v4i v = rr[i];
+      v[0] ^= rflip; v[1] ^= rflip; v[2] ^= rflip; v[3] ^= rflip;
+      *(lds_v4i*)(Ws + (q >> 1) * (PCIN_PAD * 32) + c * 32 + 16 * (q & 1)) = v;
     }
     __syncthreads();
   }
   STAMP2();
 
   // ------------------------------------------------------------------------------------------ 1x1 GEMM passes of 256 channels
-  const unsigned char* const xd_lane = Xd + sep2_a_lane_off(lane);
-  const unsigned char* const xr_lane = Ws + sep2_a_lane_off(lane);
+  const lds_u8* const xd_lane = Xd + sep2_a_lane_off(lane);
+  const lds_u8* const xr_lane = Ws + sep2_a_lane_off(lane);
   const bool full_out = t0 + TT <= lim;
-  // per-pane scalars once (the kernarg block is large; re-reading it inside the pass loop costs SGPRs and waits)
-  const int8_t* const pw = EP == EP2_RESADD1 ? p.panes[0].w : p.w;
-  const int pcin_pad = EP == EP2_RESADD1 ? p.panes[0].cin_pad : cin_pad;
-  const int32_t* const pbias = EP == EP2_RESADD1 ? p.panes[0].bias : p.bias;
-  const double* const pm = EP == EP2_RESADD1 ? p.panes[0].m : nullptr;
-  const float* const psb = EP == EP2_RESADD1 ? p.panes[0].sb : nullptr;
-  int32_t* const pdbg = EP == EP2_RESADD1 ? p.panes[0].acc_dbg : nullptr;
+  int32_t* const pdbg = RES ? p.panes[0].acc_dbg : nullptr;
   const int qlo = f_relu ? max(e.qlo, 0) : e.qlo, qhi = e.qhi;
-#pragma unroll 1
-  for (int cbase = 0; cbase < cout_pad; cbase += 256) {
-    const int co = cbase + co_l;
-    const int cor = co < cout_pad ? co : 0;                  // waves beyond cout_pad (multiple of 128) redo tile 0, stores are off
-    const bool co_ok = co < ecout;
-    const int con = cbase + 256 + co_l < cout_pad ? cbase + 256 + co_l : 0;   // next pass (or a harmless re-read of tile 0)
-    const v4i* const wmain = w_frag(p.w, cin_pad, cor, 0);
-    const v4i* const wnext = w_frag(p.w, cin_pad, con, 0);
-    const v4i* const wpane = w_frag(pw, pcin_pad, cor, 0);
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int cbase = 256 * ps;
+    const int co = cbase + co_l, cor = co;
+    constexpr bool co_ok = true;
+    const bool more = ps + 1 < NP;
+    const v4i* const wnext = more ? w_frag(p.w, CIN_PAD, co + 256, 0) : nullptr;   // this wave's rows in the next pass
+    const v4i* const wpane = RES ? w_frag(p.panes[0].w, PCIN_PAD, cor, 0) : nullptr;
+    const Sep2PassP& pp = pps[ps];
     int rl = lim - t0 - 4 * h;                               // frames of this lane's registers below rl are valid;
     asm volatile("" : "+v"(rl));                             // opaque: keeps 16 MT masks out of the loop-invariant code
     v16i acc[MT];
-    {
-      const int bias = p.bias[cor];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = bias;
-    }
-    sep2_gemm<MT>(acc, wb0, wb1, xd_lane, cin_pad * 32, wmain, ng, EP == EP2_RESADD1 ? wpane : wnext);
+      for (int r = 0; r < 16; ++r) acc[mt][r] = pp.bias;
+    // once multiplied, a slab group is re-requested: with the residual conv's group (beyond its K depth: the next
+    // pass's main group); after the residual GEMM with the next pass's main groups that are still missing
+    if constexpr (RES) sep2_gemm<MT, NG, (NGP < NG ? NGP : NG)>(acc, wf, xd_lane, CIN_PAD * 32, wpane, wnext);
+    else sep2_gemm<MT, NG, 0>(acc, wf, xd_lane, CIN_PAD * 32, nullptr, wnext);
     STAMP2();
     // accumulator hooks, then masked frames (t >= lim): an accumulator of 0 requantises to 0 for every consumer
     // (lo <= 0 <= hi) and through res_act
@@ -376,7 +460,7 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a[mt][r] = z_roundtrip(a[mt][r], sb, EP == EP2_PLAIN && f_relu);
+            for (int r = 0; r < 16; ++r) a[mt][r] = z_roundtrip(a[mt][r], sb, !RES && f_relu);
         }
       }
     };
@@ -393,33 +477,26 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
       if (co_ok) *(v4i*)((int8_t*)optr + ((size_t)b * ecout + co) * eTp + t0 + 32 * mt + 16 * h) = pk;
     };
 
-    if (EP == EP2_RESADD1) {
+    if constexpr (RES) {
       // res_act (jasper.py:680-682; quant_utils.py:187-214): q = clamp(rq(out) + rq(res)), then ReLU (folded into qlo)
-      finish(acc, e.acc_dbg, f_exact ? e.sb[cor] : 1.0f);
-      {
-        const double Mm = e.m_main[cor];
+      finish(acc, e.acc_dbg, pp.sbm);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mt][r] = rq_rint(acc[mt][r], Mm);
-      }
+        for (int r = 0; r < 16; ++r) acc[mt][r] = rq_rint(acc[mt][r], pp.Mm);
       v16i accp[MT];
-      {
-        const int bv = pbias[cor];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) accp[mt][r] = bv;
-      }
-      sep2_gemm<MT>(accp, wb0, wb1, xr_lane, pcin_pad * 32, wpane, pcin_pad >> 7, wnext);
+        for (int r = 0; r < 16; ++r) accp[mt][r] = pp.pbias;
+      sep2_gemm<MT, NGP, (NGP < NG ? NGP : NG)>(accp, wf, xr_lane, PCIN_PAD * 32, wnext, nullptr);
       STAMP2();
-      finish(accp, pdbg, f_exact ? psb[cor] : 1.0f);
-      const double Mp = pm[cor];
+      finish(accp, pdbg, pp.sbp);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         int z[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = med3i(acc[mt][r] + rq_rint(accp[mt][r], Mp), qlo, qhi);
+        for (int r = 0; r < 16; ++r) z[r] = med3i(acc[mt][r] + rq_rint(accp[mt][r], pp.Mp), qlo, qhi);
 #pragma unroll 1
         for (int j = 0; j < n_outs; ++j) {
           const OutP& o = e.outs[j];
@@ -437,18 +514,19 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
       }
     } else {
       // ReLU is folded into the consumers' lower clamp bound by the packer (M > 0: rint(z M) <= 0 for z <= 0)
-      finish(acc, e.acc_dbg, f_exact ? e.sb[cor] : 1.0f);
-#pragma unroll 1
-      for (int j = 0; j < n_outs; ++j) {
-        const OutP& o = e.outs[j];
-        const double Mo = o.mtab[cor];
-        const int olo = o.lo, ohi = o.hi;
+      finish(acc, e.acc_dbg, pp.sbm);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          int q[16];
+      for (int j = 0; j < QASR_MAX_OUTS; ++j) {
+        if (j < n_outs) {
+          const OutP& o = e.outs[j];
+          const int olo = o.lo, ohi = o.hi;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) q[r] = rq_clamp(acc[mt][r], Mo, olo, ohi);
-          store16(o.ptr, mt, q);
+          for (int mt = 0; mt < MT; ++mt) {
+            int q[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[r] = rq_clamp(acc[mt][r], pp.Mo[j], olo, ohi);
+            store16(o.ptr, mt, q);
+          }
         }
       }
     }
@@ -464,30 +542,41 @@ static inline size_t sep2_smem_bytes(const SepP& p) {
   const size_t xd = (size_t)TT * p.cin_pad;
   size_t ws = (size_t)std::min(SEP2_CH, p.cin) * G::WP + 64;
   if (p.n_panes == 1) ws = std::max(ws, (size_t)TT * p.panes[0].cin_pad);
-  return xd + ws;
+  return xd + G::TAPB + 64 + ws;
 }
+
+// (taps, cin groups, residual cin groups) k_sep2 is instantiated for: QuartzNet's separable layers (256 / 512 channels);
+// X(K, NG, NGP, NP)  (NP = passes of 256 output channels)
+#define SEP2_INSTANCES(X) \
+  X(33, 2, 0, 1) X(39, 2, 0, 1) X(51, 2, 0, 2) X(51, 4, 0, 2) X(63, 4, 0, 2) X(75, 4, 0, 2) \
+  X(33, 2, 2, 1) X(39, 2, 2, 1) X(51, 4, 2, 2) X(51, 4, 4, 2) X(63, 4, 4, 2) X(75, 4, 4, 2)
 
 // Shapes k_sep2 is built for; everything else stays on k_sep.
 static inline bool sep2_shape_ok(const SepP& p) {
   const EpiP& e = p.e;
-  if (p.K <= 0 || p.dilation != 1 || p.dense_k > 1) return false;
-  if (!(p.K == 33 || p.K == 39 || p.K == 51 || p.K == 63 || p.K == 75 || p.K == 11 || p.K == 13)) return false;
-  if ((p.cin_pad != 256 && p.cin_pad != 512) || e.cout > 512) return false;   // even counts of 128-deep K groups
+  if (p.K <= 0 || p.dilation != 1 || p.dense_k > 1 || p.cin_pad & 127 || e.cout > 512) return false;
   if (e.flags & (QASR_F_LOGITS | QASR_F_WIDE_RQ)) return false;
   if (e.n_outs < 1) return false;
+  int ngp = 0;
   if (e.flags & QASR_F_RESADD) {
-    if (p.n_panes != 1 || (p.panes[0].cin_pad != 256 && p.panes[0].cin_pad != 512)) return false;
+    if (p.n_panes != 1 || p.panes[0].cin_pad & 127) return false;
+    ngp = p.panes[0].cin_pad >> 7;
     for (int j = 0; j < e.n_outs; ++j)
       if (e.outs[j].mode != 0 && e.outs[j].mode != 2) return false;
-    return true;
+  } else {
+    if (p.n_panes != 0) return false;
+    for (int j = 0; j < e.n_outs; ++j)
+      if (e.outs[j].mode != 1) return false;
   }
-  if (p.n_panes != 0) return false;
-  for (int j = 0; j < e.n_outs; ++j)
-    if (e.outs[j].mode != 1) return false;
-  return true;
+  if (p.cin != p.cin_pad || (e.cout & 255) || (ngp && p.panes[0].cin != p.panes[0].cin_pad)) return false;   // exact shapes
+  const int ng = p.cin_pad >> 7, np = (e.cout + 255) / 256;
+#define SEP2_MATCH(K_, NG_, NGP_, NP_) if (p.K == K_ && ng == NG_ && ngp == NGP_ && np == NP_) return true;
+  SEP2_INSTANCES(SEP2_MATCH)
+#undef SEP2_MATCH
+  return false;
 }
 
-template <int K, int EP, bool DBG, int TT>
+template <int K, int NG, int NGP, int NP, bool DBG, int TT>
 static int launch_sep2_v(hipStream_t s, const SepP& p) {
   const size_t smem = sep2_smem_bytes<K, TT>(p);
   if (smem > 160 * 1024 || p.e.B < 1 || p.e.Tp % TT || !p.x || !p.w || !p.wdw2) return QASR_ERR_ARG;
@@ -495,34 +584,24 @@ static int launch_sep2_v(hipStream_t s, const SepP& p) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (attr_dev != dev) {
-    (void)hipFuncSetAttribute((const void*)k_sep2<K, EP, DBG, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_sep2<K, NG, NGP, NP, DBG, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_dev = dev;
   }
   SepP q = p;
   q.prof = g_prof;
-  hipLaunchKernelGGL((k_sep2<K, EP, DBG, TT>), dim3(p.e.B, p.e.Tp / TT, 1), dim3(SEP2_NT), smem, s, q);
+  hipLaunchKernelGGL((k_sep2<K, NG, NGP, NP, DBG, TT>), dim3(p.e.B, p.e.Tp / TT, 1), dim3(SEP2_NT), smem, s, q);
   return QASR_OK;
 }
 
-template <int K, bool DBG, int TT>
-static int launch_sep2_k(hipStream_t s, const SepP& p) {
-  if (p.e.flags & QASR_F_RESADD) return launch_sep2_v<K, EP2_RESADD1, DBG, TT>(s, p);
-  return launch_sep2_v<K, EP2_PLAIN, DBG, TT>(s, p);
-}
-
-// all kernel-size instantiations of one (tile, debug) pair; QASR_ERR_UNSUPPORTED for a tap count without one
+// all instantiations of one (tile, debug) pair; QASR_ERR_UNSUPPORTED for a shape without one
 template <int TT, bool DBG>
 int launch_sep2_inst(hipStream_t s, const SepP& p) {
-  switch (p.K) {
-    case 11: return launch_sep2_k<11, DBG, TT>(s, p);
-    case 13: return launch_sep2_k<13, DBG, TT>(s, p);
-    case 33: return launch_sep2_k<33, DBG, TT>(s, p);
-    case 39: return launch_sep2_k<39, DBG, TT>(s, p);
-    case 51: return launch_sep2_k<51, DBG, TT>(s, p);
-    case 63: return launch_sep2_k<63, DBG, TT>(s, p);
-    case 75: return launch_sep2_k<75, DBG, TT>(s, p);
-    default: return QASR_ERR_UNSUPPORTED;
-  }
+  const int ng = p.cin_pad >> 7, ngp = (p.e.flags & QASR_F_RESADD) ? (p.panes[0].cin_pad >> 7) : 0, np = (p.e.cout + 255) / 256;
+#define SEP2_LAUNCH(K_, NG_, NGP_, NP_) \
+  if (p.K == K_ && ng == NG_ && ngp == NGP_ && np == NP_) return launch_sep2_v<K_, NG_, NGP_, NP_, DBG, TT>(s, p);
+  SEP2_INSTANCES(SEP2_LAUNCH)
+#undef SEP2_LAUNCH
+  return QASR_ERR_UNSUPPORTED;
 }
 
 }  // namespace qasr
