@@ -5,17 +5,22 @@ One "step" = one pass of the hot path over one batch resident in HBM:
     synthetic 16 kHz audio [32, 80000] (5 s each -> 500 valid mel frames)
     -> HIP mel front-end -> integer QuartzNet15x5 encoder (w8a8, percentile 99.996 calibration)
     -> CTC decoder -> log-softmax + greedy argmax tokens            (all in libqasr_hip.so)
-With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank runs its own 32-utterance
-shard (weak scaling); rank 0 calibrates + packs the model and broadcasts the packed int weights over RCCL,
-and each step ends with an RCCL gather of the greedy tokens to rank 0.
+`--gpus N`: one rank per GPU, every rank runs its own 32-utterance shard (weak scaling); rank 0 calibrates + packs the
+model and broadcasts the packed int weights over RCCL, and each step ends with an RCCL gather of the greedy tokens to
+rank 0.  Started without a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the parent - before anything touches
+the GPU - starts the N ranks itself as child processes and relays rank 0's JSON line; started by torch.distributed.run
+it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
-Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the launch stream (each op
-replayed 20x between one event pair) for the kernel instantiation with the largest share of the step (a k_sep<K,...> fused separable layer); `cpu_baseline`
-times the reference's fake-quant CPU op sequence (oracle/fakequant_torch.py) on the host cores (N=1 only).
-"""
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the launch stream (each op replayed 20x
+between one event pair) for the kernel instantiation with the largest share of the step; `cpu_baseline` times the
+reference's fake-quant CPU op sequence (oracle/fakequant_torch.py) on the host cores (N=1 only).
+`--config w6a6|jasper` runs BASELINE.json's configurations 3 / 4 through the same loop (config 2 is the default and the
+headline)."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,13 +32,82 @@ for p in (os.path.join(ROOT, 'q-asr_amd'), ROOT):
 # steps in flight live on separate HIP streams; ROCm maps streams onto 4 hardware queues by default
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 PEAK_INT8_OPS = 256 * 4 * 2048 * 2.4e9       # 256 CUs x 4 SIMDs x 1024 MAC/clk (v_mfma_i32_32x32x32_i8) x 2.4 GHz
 PEAK_HBM = 8.0e12
+SAMPLES, FRAMES = 80000, 500
+
+CONFIGS = {
+    # name: (model, weight bits, act bits, batch per GPU, default steps in flight, BASELINE.json configuration)
+    'quartznet': ('QuartzNet15x5Base-En', 8, 8, 32, 4, 2),
+    'w6a6': ('QuartzNet15x5Base-En', 6, 6, 32, 4, 3),
+    'jasper': ('Jasper10x5Dr-En', 8, 8, 64, 2, 4),
+}
+
+_T0 = time.time()
 
 
+def log(msg):
+    print(f'[bench {time.time() - _T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='quartznet',
+                    help='quartznet = BASELINE.json config 2 (headline); w6a6 = config 3; jasper = config 4')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--tile', type=int, default=0, choices=[0, 32, 64],
+                    help='frames per work-group of the separable-layer kernels: 32 = lowest single-step latency, 64 = less '
+                         'weight/halo traffic per frame but half the work-groups; 0 = 64 when more than one step is in flight')
+    ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel instead of replaying the captured hipGraph')
+    ap.add_argument('--whole-utterance', action='store_true', help='use the k_utt kernels (one work-group per utterance)')
+    ap.add_argument('--streams', type=int, default=int(os.environ.get('QASR_BENCH_STREAMS', 0)),
+                    help='independent steps in flight per GPU (each on its own HIP stream + engine arena); 0 = the config default')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='rank plumbing only (launcher, process group, blob broadcast, per-step token gather) on synthetic '
+                         'payloads: no model, no engine, no GPU needed (gloo when no GPU is visible)')
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks as child processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set) BEFORE this process touches the GPU, relay rank 0's JSON line, fail if any rank fails.  The parent
+    never initialises HIP (torch.cuda.device_count() does not) and never re-executes itself."""
+    import torch
+    n_vis = torch.cuda.device_count()
+    if not args.dry_run and n_vis < args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but only {n_vis} GPU(s) visible', file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        print(f'bench.py: rank exit codes {rcs}', file=sys.stderr)
+        return max(1, max(abs(rc) for rc in rcs))
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ roofline helpers
 def pmc_traffic():
     """HBM bytes per dispatch by kernel, from the newest PMC summaries committed under profiles/ (written by
     profiles/collect.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, KB per dispatch).  gfx950 tallies a
@@ -54,15 +128,6 @@ def pmc_traffic():
             if m:
                 out[m.group(1)] = out.get(m.group(1), 0.0) + mult * 1024.0 * float(m.group(4))
     return out, src
-MODEL = 'QuartzNet15x5Base-En'
-BATCH, SAMPLES, FRAMES = 32, 80000, 500
-
-
-_T0 = time.time()
-
-
-def log(msg):
-    print(f'[bench {time.time() - _T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
 
 
 def host_cores():
@@ -79,19 +144,21 @@ def host_cores():
 
 def algorithmic_work(cfg, B, T_out):
     """Ops (2 per MAC) per forward by kernel class, from the topology (273.4 GOP MFMA-class,
-    28.2 GOP depthwise at B=32, T=500->250) and the minimal int8 activation bytes of the depthwise class."""
+    28.2 GOP depthwise at B=32, T=500->250) and the minimal int8 activation bytes (each conv reads its input once and
+    writes its output once, weights once)."""
     from qasr import topology
-    mfma = dw = dw_bytes = 0
+    mfma = dw = act_bytes = w_bytes = 0
     for sites in topology.conv_plan(cfg):
         for s in sites:
             macs = B * T_out * s.cout * (s.cin // s.groups) * s.kernel
             if s.role == 'dw':
                 dw += 2 * macs
-                dw_bytes += B * s.cout * T_out * (2 if s.stride == 1 else 3)
             else:
                 mfma += 2 * macs
+            act_bytes += B * T_out * (s.cin * s.stride + s.cout)
+            w_bytes += s.cout * (s.cin // s.groups) * s.kernel
     mfma += 2 * B * T_out * cfg.blocks[-1].filters * (cfg.num_classes + 1)
-    return mfma, dw, dw_bytes
+    return mfma, dw, act_bytes + w_bytes
 
 
 def dominant_kernel_roofline(eng, cfg, meta, ms, B, T):
@@ -152,20 +219,22 @@ def dominant_kernel_roofline(eng, cfg, meta, ms, B, T):
         'per_kernel_ms_per_step': {k: round(v, 4) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])},
         'timing': 'each op replayed 20x between one HIP event pair on the launch stream, no other work in flight',
         'traffic_source': 'rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes, per '
-                          f'dispatch average, bytes (profiles/{traffic_src}_pmc_*.txt); null = not collected'}
+                          f'dispatch average, bytes, read from the committed summary profiles/{traffic_src}_pmc_*.txt '
+                          '(not collected in this run); null = that summary has no row for this kernel'}
     return out
 
 
-def build_model(device):
-    """Random-init QuartzNet15x5 (no network for checkpoints), calibrated exactly like inference.py does."""
+def build_model(device, model_name, wbit, abit):
+    """Random-init model (no network for checkpoints), calibrated exactly like inference.py does."""
+    import torch
     import nemo.quantization.utils.quantize_model as qm
     from nemo.collections.asr.models import EncDecCTCModel
     from qasr import pack, synth
     torch.set_grad_enabled(False)
-    m = EncDecCTCModel.from_synthetic(MODEL, seed=0).to(device)
+    m = EncDecCTCModel.from_synthetic(model_name, seed=0).to(device)
     m.eval()
-    m.set_quant_bit(8, mode='weight')
-    m.set_quant_bit(8, mode='act')
+    m.set_quant_bit(wbit, mode='weight')
+    m.set_quant_bit(abit, mode='act')
     qm.set_percentile(m, 99.996)
     m.encoder.bn_folding()
     qm.calibrate(m)
@@ -182,33 +251,59 @@ def build_model(device):
     return blob, meta, f.fb[0].detach().cpu().contiguous(), f.window.detach().cpu().contiguous(), inputs[2], inputs[3]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--tile', type=int, default=0, choices=[0, 32, 64],
-                    help='k_sep frames per work-group: 32 = lowest single-step latency, 64 = less weight/halo traffic '
-                         'per frame but half the work-groups; 0 = 64 when more than one step is in flight')
-    ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel instead of replaying the captured hipGraph')
-    ap.add_argument('--whole-utterance', action='store_true', help='use the k_utt kernels (one work-group per utterance)')
-    ap.add_argument('--streams', type=int, default=int(os.environ.get('QASR_BENCH_STREAMS', 4)),
-                    help='independent steps in flight per GPU (each on its own HIP stream + engine arena)')
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ one rank
+def run_dry(args, rank, world):
+    """Rank plumbing without the engine: process group, blob broadcast, per-step token gather, rank census."""
+    import torch
+    from qasr import dist as qdist
+    use_gpu = torch.cuda.is_available() and os.environ.get('QASR_BENCH_BACKEND', 'nccl') == 'nccl'
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0))) if use_gpu else torch.device('cpu')
+    seen = 1
+    if world > 1:
+        import torch.distributed as dist
+        if use_gpu:
+            torch.cuda.set_device(dev)
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
+        blob = qdist.broadcast_bytes(bytes(range(256)) * 64 if rank == 0 else None, 0, dev)
+        assert blob == bytes(range(256)) * 64
+        gathered = [torch.empty(4, 8, dtype=torch.int32, device=dev) for _ in range(world)] if rank == 0 else None
+        for i in range(args.warmup + args.steps):
+            qdist.gather_tokens(torch.full((4, 8), 100 * rank + i, dtype=torch.int32, device=dev), 0, gathered)
+            if rank == 0:
+                assert [int(g[0, 0]) for g in gathered] == [100 * r + i for r in range(world)]
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones)
+        seen = int(ones[0])
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'metric': 'dry-run (rank plumbing only)', 'value': None, 'n_gpus': world, 'n_ranks_seen': seen,
+                          'steps': args.steps, 'warmup': args.warmup, 'dry_run': True,
+                          'backend': 'nccl' if use_gpu else 'gloo'}))
 
+
+def run(args):
+    import numpy as np
+    import torch
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.dry_run:
+        return run_dry(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the integer engine has no CPU fallback')
+    model_name, wbit, abit, BATCH, S_default, baseline_cfg = CONFIGS[args.config]
     # QASR_BENCH_BACKEND=gloo rehearses the N>1 control flow on a one-GPU box: every rank uses GPU 0 and the two
     # exchange steps go through host memory.  The measured configuration is always nccl (= RCCL), one GPU per rank.
     backend = os.environ.get('QASR_BENCH_BACKEND', 'nccl')
     if backend != 'nccl':
         local = local % max(1, torch.cuda.device_count())
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f'rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     comm_dev = dev if backend == 'nccl' else torch.device('cpu')
@@ -222,96 +317,131 @@ def main():
             dist.init_process_group(backend)
 
     from qasr import engine, synth, topology
-    engine.load_library()
-    cfg = topology.MODELS[MODEL]()
+    from qasr import dist as qdist
+    lib = engine.load_library()
+    cfg = topology.MODELS[model_name]()
 
     # rank 0 calibrates + packs; the packed int weights travel to the other ranks over RCCL/xGMI
-    from qasr import dist as qdist
     blob = meta = None
     fb, window = torch.zeros(64, 257), torch.zeros(320)
     if rank == 0:
-        blob, meta, fb, window, amin, amax = build_model(dev)
+        blob, meta, fb, window, amin, amax = build_model(dev, model_name, wbit, abit)
+    n_ranks_seen = 1
     if world > 1:
         blob = qdist.broadcast_bytes(blob, 0, comm_dev)
         fb, window = qdist.broadcast_tensors([fb, window], 0, comm_dev)
+        ones = torch.ones(1, dtype=torch.int64, device=comm_dev)
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones[0])
     fb, window = fb.to(dev), window.to(dev)
-    # throughput mode: consecutive steps are independent batches, so S of them are kept in flight, each on its own
-    # HIP stream with its own engine arena (kernels of different steps overlap each other's launch gaps and tails)
-    S = max(1, args.streams)
-    tile = args.tile or (64 if S > 1 else 32)
-    engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance, wide_tiles=(tile == 64),
-                          graph=not args.no_graph) for _ in range(S)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    eng = engs[0]
-    log(f'{S} engine(s) ready ({len(blob) / 1e6:.1f} MB blob); warm-up')
 
-    audio = torch.from_numpy(synth.make_audio(BATCH, SAMPLES, seed=100 + rank)).to(dev)
+    T_pad = lib.qasr_frontend_frames(SAMPLES, 16)
+    lib_ws = lib.qasr_frontend_workspace_bytes(BATCH, SAMPLES, 64)
+
+    def make_lane(S, tile):
+        """S steps in flight: per step in flight an engine (own arena), a HIP stream, its own audio batch and its own
+        feature / length / token buffers (stable pointers: the forward replays as one hipGraph launch)."""
+        engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance, wide_tiles=(tile == 64),
+                              graph=not args.no_graph) for _ in range(S)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        T_out = engs[0].out_frames(T_pad)
+        audio = [torch.from_numpy(synth.make_audio(BATCH, SAMPLES, seed=100 + 16 * rank + k)).to(dev) for k in range(S)]
+        bufs = [dict(fe=(torch.empty(BATCH, 64, T_pad, device=dev), torch.empty(BATCH, dtype=torch.int32, device=dev),
+                         torch.empty(max(lib_ws, 16), dtype=torch.uint8, device=dev)),
+                     out=(None, torch.empty(BATCH, T_out, dtype=torch.int32, device=dev),
+                          torch.empty(BATCH, dtype=torch.int32, device=dev)),
+                     gathered=None) for _ in range(S)]
+        return dict(S=S, engs=engs, streams=streams, audio=audio, bufs=bufs, T_out=T_out)
+
     alen = torch.full((BATCH,), SAMPLES, dtype=torch.int32, device=dev)
-    T_out = eng.out_frames(engine.load_library().qasr_frontend_frames(SAMPLES, 16))
-    gathered = [torch.empty(BATCH, T_out, dtype=torch.int32, device=comm_dev) for _ in range(world)] if rank == 0 else None
 
-    # every step in flight owns its buffers (features, lengths, tokens): stable pointers let the engine replay its
-    # forward as one hipGraph launch instead of ~90 kernel launches
-    T_pad = engine.load_library().qasr_frontend_frames(SAMPLES, 16)
-    lib_ws = engine.load_library().qasr_frontend_workspace_bytes(BATCH, SAMPLES, 64)
-    bufs = [dict(fe=(torch.empty(BATCH, 64, T_pad, device=dev), torch.empty(BATCH, dtype=torch.int32, device=dev),
-                     torch.empty(max(lib_ws, 16), dtype=torch.uint8, device=dev)),
-                 out=(None, torch.empty(BATCH, T_out, dtype=torch.int32, device=dev),
-                      torch.empty(BATCH, dtype=torch.int32, device=dev))) for _ in range(S)]
-
-    def step(i):
-        k = i % S
-        with torch.cuda.stream(streams[k]):
-            feats, flen = engine.frontend_mel(audio, alen, fb, window, 0.97, 16, out=bufs[k]['fe'])
-            _, tokens, _ = engs[k].forward(feats, flen, want_logp=False, out=bufs[k]['out'])
+    def step(lane, i, gathered=None):
+        k = i % lane['S']
+        b = lane['bufs'][k]
+        with torch.cuda.stream(lane['streams'][k]):
+            if b['gathered'] is not None:                    # the gather of this buffer set's previous step read `tokens`
+                lane['streams'][k].wait_event(b['gathered'])
+            feats, flen = engine.frontend_mel(lane['audio'][k], alen, fb, window, 0.97, 16, out=b['fe'])
+            _, tokens, _ = lane['engs'][k].forward(feats, flen, want_logp=False, out=b['out'])
             done = torch.cuda.Event()
-            done.record(streams[k])
+            done.record(lane['streams'][k])
         if world > 1:
             # one communicator: the per-step gathers are issued in step order on the default stream, each behind its
             # step's compute stream; compute of later steps keeps running on the other streams
-            torch.cuda.current_stream().wait_event(done)
-            tokens.record_stream(torch.cuda.current_stream())
+            cur = torch.cuda.current_stream()
+            cur.wait_event(done)
             qdist.gather_tokens(tokens if backend == 'nccl' else tokens.cpu(), 0, gathered)
+            b['gathered'] = torch.cuda.Event()
+            b['gathered'].record(cur)
         return tokens
 
-    # one-time setup, like the model build above: each engine's first forward launches kernel by kernel, the second is
-    # captured into its hipGraph; only then do the W warm-up steps and the K timed steps run (all as graph replays)
-    for i in range(2 * S):
-        step(i)
-    torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    last = []
-    for i in range(args.steps):
-        tokens = step(i)
-        last = (last + [tokens])[-S:]
-    t_enq = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    # every step decodes the same batch: the steps that were in flight together must agree bit for bit
-    if not all(torch.equal(t_, last[0]) for t_ in last):
-        raise SystemExit('bench: concurrent steps produced different tokens')
+    def timed(lane, steps, warmup, gathered=None):
+        # one-time setup, like the model build: each engine's first forward launches kernel by kernel, the second is
+        # captured into its hipGraph; the serial results of that phase are the reference every later step must reproduce
+        S = lane['S']
+        ref = []
+        for i in range(2 * S):
+            t_ = step(lane, i, gathered)
+            torch.cuda.synchronize()
+            if i >= S:
+                ref.append(t_.clone())
+        for i in range(warmup):
+            step(lane, i, gathered)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = {}
+        for i in range(steps):
+            last[i % S] = step(lane, i, gathered)
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        # every step in flight decodes its own batch: each must reproduce its serial result bit for bit
+        for k, t_ in last.items():
+            if not torch.equal(t_, ref[k]):
+                raise SystemExit(f'bench: stream {k} produced different tokens with other steps in flight')
+        if world > 1 and rank == 0 and gathered is not None:
+            torch.cuda.synchronize()
+            k_last = (steps - 1) % S
+            if not torch.equal(gathered[0].to(last[k_last].device), last[k_last]):
+                raise SystemExit('bench: tokens gathered from rank 0 differ from the local ones')
+        return dt, t_enq, last[(steps - 1) % S]
+
+    # throughput mode: consecutive steps are independent batches, so S of them are kept in flight, each on its own
+    # HIP stream with its own engine arena (kernels of different steps overlap each other's launch gaps and tails)
+    S = max(1, args.streams or S_default)
+    tile = args.tile or (64 if S > 1 else 32)
+    lane = make_lane(S, tile)
+    eng = lane['engs'][0]
+    T_out = lane['T_out']
+    log(f'{S} engine(s) ready ({len(blob) / 1e6:.1f} MB blob); warm-up')
+    gathered = [torch.empty(BATCH, T_out, dtype=torch.int32, device=comm_dev) for _ in range(world)] if rank == 0 else None
+    dt, t_enq, tokens = timed(lane, args.steps, args.warmup, gathered)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
     audio_s = world * BATCH * SAMPLES / 16000.0 * args.steps
     log(f'timed {args.steps} steps: {1e3 * dt / args.steps:.3f} ms/step (host enqueue {1e3 * t_enq / args.steps:.3f} ms/step)')
+    metric = ('RTFx (audio-sec/wall-sec) QuartzNet15x5 int8 bs32' if args.config == 'quartznet'
+              else f'RTFx (audio-sec/wall-sec) {model_name} w{wbit}a{abit} bs{BATCH}')
     result = {
-        'metric': 'RTFx (audio-sec/wall-sec) QuartzNet15x5 int8 bs32', 'value': audio_s / dt, 'unit': 'audio-s/wall-s',
+        'metric': metric, 'value': audio_s / dt, 'unit': 'audio-s/wall-s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8 (s8 x s8 -> i32 on MFMA; float32/float64 fixed-point requant)',
-        'data': 'synthetic',
-        'config': {'workload': 'QuartzNet15x5Base-En w8a8 percentile=99.996, bs=32/GPU, 5 s synthetic 16 kHz audio '
-                               '(500 mel frames): HIP mel front-end + integer encoder + CTC decoder + greedy argmax',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': f'int{wbit} (s8 x s8 -> i32 on MFMA; float64 fixed-point requant)',
+        'data': 'synthetic', 'n_ranks_seen': n_ranks_seen,
+        'config': {'workload': f'BASELINE.json config {baseline_cfg}: {model_name} w{wbit}a{abit} percentile=99.996, bs={BATCH}/GPU, '
+                               '5 s synthetic 16 kHz audio (500 mel frames): HIP mel front-end + integer encoder + CTC '
+                               'decoder + greedy argmax',
                    'global_batch': BATCH * world, 'seq_len': FRAMES, 'weights': 'random-init (qasr.synth, seed 0)',
-                   'steps_in_flight': S, 'hip_graph': not args.no_graph, 'kernels': 'k_utt' if args.whole_utterance else f'k_sep, {tile}-frame tiles', 'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + token gather' if world > 1 else ''),
+                   'steps_in_flight': S, 'inputs': 'one audio batch per step in flight (different seeds)',
+                   'hip_graph': not args.no_graph,
+                   'kernels': 'k_utt' if args.whole_utterance else f'k_sep2 / k_sep, {tile}-frame tiles',
+                   'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + token gather' if world > 1 else ''),
                    'wer': 'not measurable here: no LibriSpeech / checkpoint in the image'},
     }
 
@@ -319,50 +449,75 @@ def main():
         # ---- roofline of the dominant kernel, HIP events on the launch stream ---------------------------------
         # every op is replayed 20x back to back between one HIP event pair on the launch stream
         # (qasr_engine_time_ops); buffers hold the real activations of the last timed step
+        torch.cuda.synchronize()
         ms = eng.time_ops(reps=20).astype(np.float64)
         result['roofline'] = dominant_kernel_roofline(eng, cfg, meta, ms, BATCH, FRAMES // 2)
-        mfma_ops, dw_ops, _ = algorithmic_work(cfg, BATCH, FRAMES // 2)
+        mfma_ops, dw_ops, step_bytes = algorithmic_work(cfg, BATCH, FRAMES // 2)
         # whole-step view (all launches, steps in flight as timed): SURVEY §8d bytes = every conv reads its int8 input
-        # once, writes its output once, weights once (1065.9 + 18.85 MB at B=32, T'=250)
-        step_bytes = 1065.9e6 * BATCH / 32 + 18.85e6
+        # once, writes its output once, weights once
         result['roofline']['other'].update(step_mfma_class_gop=mfma_ops / 1e9, step_depthwise_gop=dw_ops / 1e9,
                                            step_mfma_class_top_s=mfma_ops / (dt / args.steps) / 1e12,
+                                           step_mfma_frac=mfma_ops / (dt / args.steps) / PEAK_INT8_OPS,
                                            step_algorithmic_gb_s=step_bytes / (dt / args.steps) / 1e9,
                                            step_hbm_frac=step_bytes / (dt / args.steps) / PEAK_HBM,
-                                           work_groups_per_launch=BATCH * 256 // tile,
-                                           note='a 64-frame-tile launch fills 128 of the 256 CUs; the bench keeps two '
-                                                'such launches (of different steps) on the chip at a time')
+                                           work_groups_per_launch=BATCH * 256 // tile)
+    for e_ in lane['engs']:
+        e_.close()
 
+    if world == 1 and rank == 0:
+        # ---- one step in flight (32-frame tiles): the latency view of the same workload ------------------------
+        if S > 1 and not args.whole_utterance:
+            lane1 = make_lane(1, 32)
+            dt1, _, _ = timed(lane1, args.steps, args.warmup)
+            result['single_stream_ms_per_step'] = 1e3 * dt1 / args.steps
+            result['single_stream_rtfx'] = BATCH * SAMPLES / 16000.0 * args.steps / dt1
+            log(f'one step in flight, 32-frame tiles: {1e3 * dt1 / args.steps:.3f} ms/step')
+            for e_ in lane1['engs']:
+                e_.close()
         # ---- CPU baseline: the reference's fake-quant op sequence on this host's cores (N=1 only) --------------
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             from oracle.fakequant_torch import FakeQuantNet
             cores = host_cores()
             torch.set_num_threads(cores)
             log(f'roofline pass done; CPU baseline on {cores} host threads')
             sd = synth.make_state_dict(cfg, 0)
-            net = FakeQuantNet(topology.conv_plan(cfg), cfg, sd, amin, amax, 8, 8)
-            feats, _ = engine.frontend_mel(audio, alen, fb, window, 0.97, 16)
-            x = feats[:, :, :FRAMES].cpu().numpy()
-            lens = [FRAMES] * BATCH
-            net.forward(x[:4], lens[:4])                         # warm-up on a small slice
+            net = FakeQuantNet(topology.conv_plan(cfg), cfg, sd, amin, amax, wbit, abit)
+            audio0 = torch.from_numpy(synth.make_audio(BATCH, SAMPLES, seed=100 + 16 * rank + (args.steps - 1) % S)).to(dev)
+            feats, _ = engine.frontend_mel(audio0, alen, fb, window, 0.97, 16)
+            Bs = BATCH                                           # the same 32 x 500-frame batch the GPU timed
+            x = feats[:Bs, :, :FRAMES].cpu().numpy()
+            lens = [FRAMES] * Bs
+            n_warm, n_timed = 3, 10                              # 3 warm-up + 10 timed forwards, median
+            if args.config == 'jasper':
+                n_warm, n_timed = 1, 3
+            for _ in range(n_warm):
+                net.forward(x, lens)
             log('cpu baseline warm-up done')
-            t1 = time.perf_counter()
-            n_fwd = 2
-            for _ in range(n_fwd):
+            ts = []
+            for _ in range(n_timed):
+                t1 = time.perf_counter()
                 out = net.forward(x, lens)
-                log('cpu baseline forward done')
-            tc = (time.perf_counter() - t1) / n_fwd
-            agree = float((out['tokens'].numpy() == tokens.cpu().numpy()[:, :out['tokens'].shape[1]]).mean())
+                ts.append(time.perf_counter() - t1)
+            tc = float(np.median(ts))
+            agree = float((out['tokens'].numpy() == tokens.cpu().numpy()[:Bs, :out['tokens'].shape[1]]).mean())
             result['cpu_baseline'] = {
-                'value': BATCH * FRAMES * 0.01 / tc, 'unit': 'audio-s/wall-s', 'cores': torch.get_num_threads(),
+                'value': Bs * FRAMES * 0.01 / tc, 'unit': 'audio-s/wall-s', 'cores': torch.get_num_threads(),
                 'kind': 'port',
-                'sample': f'{n_fwd} forwards of encoder+decoder on the same 32x500-frame feature batch '
-                          f'({tc:.2f} s each; front-end excluded); token agreement with the GPU run {agree:.4f}'}
+                'sample': f'{n_warm} warm-up + {n_timed} timed forwards (median {tc:.2f} s) of encoder + decoder on the first '
+                          f'{Bs} utterances x {FRAMES} frames of the last timed batch (the whole batch); the mel front-end is NOT included '
+                          f'(features come from the GPU front-end); token agreement with the GPU run {agree:.4f}'}
+    if rank == 0:
         print(json.dumps(result))
-    for e_ in engs:
-        e_.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    run(args)
 
 
 if __name__ == '__main__':

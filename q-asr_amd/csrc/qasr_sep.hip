@@ -7,10 +7,10 @@ namespace qasr {
 
 long long* g_prof = nullptr;
 
-extern template void launch_sep_inst<32, false>(hipStream_t, const SepP&);
-extern template void launch_sep_inst<32, true>(hipStream_t, const SepP&);
-extern template void launch_sep_inst<64, false>(hipStream_t, const SepP&);
-extern template void launch_sep_inst<64, true>(hipStream_t, const SepP&);
+extern template int launch_sep_inst<32, false>(hipStream_t, const SepP&);
+extern template int launch_sep_inst<32, true>(hipStream_t, const SepP&);
+extern template int launch_sep_inst<64, false>(hipStream_t, const SepP&);
+extern template int launch_sep_inst<64, true>(hipStream_t, const SepP&);
 extern template int launch_sep2_inst<32, false>(hipStream_t, const SepP&);
 extern template int launch_sep2_inst<32, true>(hipStream_t, const SepP&);
 extern template int launch_sep2_inst<64, false>(hipStream_t, const SepP&);
@@ -50,14 +50,8 @@ int launch_sep(hipStream_t s, const SepP& p) {
     return dbg ? launch_sep2_inst<32, true>(s, p) : launch_sep2_inst<32, false>(s, p);
   }
   if (!sep_supported(p.K, p.K > 0 ? p.dilation : 1)) return QASR_ERR_UNSUPPORTED;
-  if (sep_tile_for(p) == 64) {
-    if (dbg) launch_sep_inst<64, true>(s, p);
-    else launch_sep_inst<64, false>(s, p);
-  } else {
-    if (dbg) launch_sep_inst<32, true>(s, p);
-    else launch_sep_inst<32, false>(s, p);
-  }
-  return QASR_OK;
+  if (sep_tile_for(p) == 64) return dbg ? launch_sep_inst<64, true>(s, p) : launch_sep_inst<64, false>(s, p);
+  return dbg ? launch_sep_inst<32, true>(s, p) : launch_sep_inst<32, false>(s, p);
 }
 
 }  // namespace qasr

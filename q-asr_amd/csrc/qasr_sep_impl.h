@@ -695,18 +695,29 @@ static inline size_t sep_smem_bytes(const SepP& p, int WP, int TT) {
 }
 
 template <int K, int DIL, int EP, bool DBG, int TT>
-static void launch_sep_v(hipStream_t s, const SepP& p) {
+static int launch_sep_v(hipStream_t s, const SepP& p) {
   using G = SepGeo<(K > 0 ? K : 1), DIL, TT>;
   const size_t smem = sep_smem_bytes(p, K > 0 ? G::WP : 0, TT);
-  static bool attr_set = false;
-  if (!attr_set) {
+  // launch shape checked on the host: a work-group's LDS image, the grid and every pointer the kernel dereferences
+  // unconditionally (a kernel that faults can take the whole GPU down; see DESIGN.md §4, "bring-up abort")
+  if (smem > 160 * 1024 || p.e.B < 1 || p.e.Tp < TT || p.e.Tp % TT || p.e.T > p.e.Tp || !p.x || !p.w || !p.bias || !p.e.lens ||
+      p.cin < 1 || p.cin > p.cin_pad || p.cin_pad % 128 || p.e.cout < 1 || p.n_panes < 0 || p.n_panes > QASR_MAX_PANES ||
+      (K > 0 && (!p.wdw || !p.wdw2 || !p.bias_dw || !p.m_dw)))
+    return QASR_ERR_ARG;
+  for (int k = 0; k < p.n_panes; ++k)
+    if (!p.panes[k].x || !p.panes[k].w || !p.panes[k].bias || !p.panes[k].m || p.panes[k].cin_pad % 128) return QASR_ERR_ARG;
+  static int attr_dev = -1;                                  // the attribute is per device, not per process
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (attr_dev != dev) {
     (void)hipFuncSetAttribute((const void*)k_sep<K, DIL, EP, DBG, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_dev = dev;
   }
   dim3 g(p.e.B, p.e.Tp / TT, 1);
   SepP q = p;
   q.prof = g_prof;
   hipLaunchKernelGGL((k_sep<K, DIL, EP, DBG, TT>), g, dim3(SEP_NT), smem, s, q);
+  return QASR_OK;
 }
 
 // which specialised epilogue covers this op
@@ -727,31 +738,33 @@ static inline int sep_epilogue_class(const SepP& p) {
 }
 
 template <int K, int DIL, bool DBG, int TT>
-static void launch_sep_k(hipStream_t s, const SepP& p) {
+static int launch_sep_k(hipStream_t s, const SepP& p) {
   const int ep = sep_epilogue_class(p);
-  if (ep == EP_PLAIN) launch_sep_v<K, DIL, EP_PLAIN, DBG, TT>(s, p);
-  else if (ep == EP_RESADD1) launch_sep_v<K, DIL, EP_RESADD1, DBG, TT>(s, p);
-  else launch_sep_v<K, DIL, EP_GENERIC, DBG, TT>(s, p);
+  if (ep == EP_PLAIN) return launch_sep_v<K, DIL, EP_PLAIN, DBG, TT>(s, p);
+  if (ep == EP_RESADD1) return launch_sep_v<K, DIL, EP_RESADD1, DBG, TT>(s, p);
+  return launch_sep_v<K, DIL, EP_GENERIC, DBG, TT>(s, p);
 }
 
 // all kernel-size instantiations of one (tile, debug) pair
+// QASR_ERR_UNSUPPORTED for a tap count / dilation without an instantiation (nothing is launched), QASR_ERR_ARG for a
+// launch shape the kernel must not see
 template <int TT, bool DBG>
-void launch_sep_inst(hipStream_t s, const SepP& p) {
+int launch_sep_inst(hipStream_t s, const SepP& p) {
   if (p.K > 0 && p.dilation == 2) {                         // depthwise dilation (for K == 0 `dilation` is the dense tap spacing)
-    if (p.K == 87) launch_sep_k<87, 2, DBG, TT>(s, p);
-    else if (p.K == 15) launch_sep_k<15, 2, DBG, TT>(s, p);
-    return;
+    if (p.K == 87) return launch_sep_k<87, 2, DBG, TT>(s, p);
+    if (p.K == 15) return launch_sep_k<15, 2, DBG, TT>(s, p);
+    return QASR_ERR_UNSUPPORTED;
   }
   switch (p.K) {
-    case 0: launch_sep_k<0, 1, DBG, TT>(s, p); break;
-    case 11: launch_sep_k<11, 1, DBG, TT>(s, p); break;
-    case 13: launch_sep_k<13, 1, DBG, TT>(s, p); break;
-    case 33: launch_sep_k<33, 1, DBG, TT>(s, p); break;
-    case 39: launch_sep_k<39, 1, DBG, TT>(s, p); break;
-    case 51: launch_sep_k<51, 1, DBG, TT>(s, p); break;
-    case 63: launch_sep_k<63, 1, DBG, TT>(s, p); break;
-    case 75: launch_sep_k<75, 1, DBG, TT>(s, p); break;
-    default: break;
+    case 0: return launch_sep_k<0, 1, DBG, TT>(s, p);
+    case 11: return launch_sep_k<11, 1, DBG, TT>(s, p);
+    case 13: return launch_sep_k<13, 1, DBG, TT>(s, p);
+    case 33: return launch_sep_k<33, 1, DBG, TT>(s, p);
+    case 39: return launch_sep_k<39, 1, DBG, TT>(s, p);
+    case 51: return launch_sep_k<51, 1, DBG, TT>(s, p);
+    case 63: return launch_sep_k<63, 1, DBG, TT>(s, p);
+    case 75: return launch_sep_k<75, 1, DBG, TT>(s, p);
+    default: return QASR_ERR_UNSUPPORTED;
   }
 }
 

@@ -2,5 +2,5 @@
 #include "qasr_sep_impl.h"
 
 namespace qasr {
-template void launch_sep_inst<64, true>(hipStream_t, const SepP&);
+template int launch_sep_inst<64, true>(hipStream_t, const SepP&);
 }  // namespace qasr

@@ -8,8 +8,9 @@
 Flow (identical to the reference): load model -> set bit-widths -> percentile -> BN fold -> calibrate the
 QuantAct ranges on the synthetic (mel-domain) batches in host PyTorch -> `qm.evaluate` -> evaluation loop, which
 now runs mel front-end + integer encoder/decoder in the HIP engine -> greedy CTC decode -> WER.
-`--load` accepts the reference's pickle of tensors only through a restricted loader (torch.load weights_only),
-or a .pt/.npz written by this repo; `--synthetic_calib N` generates N seeded batches instead.
+`--load` reads what the reference's synthesize.py writes (`pickle.dump([x.cpu() ...])`, synthesize.py:103-104) through
+a restricted unpickler that can only rebuild tensors, or a .pt / .npz written by this repo; `--synthetic_calib N`
+generates N seeded batches instead.
 """
 import os
 import sys
@@ -30,12 +31,7 @@ if not torch.cuda.is_available():
     raise Exception("Current implementation only supports GPU (MI355X / ROCm)")
 
 
-def load_synthetic(path):
-    if path.endswith('.npz'):
-        d = np.load(path)
-        return [torch.from_numpy(d[k]) for k in sorted(d.files)]
-    data = torch.load(path, map_location='cpu', weights_only=True)   # never unpickles arbitrary objects
-    return list(data)
+from qasr.calib_io import load_synthetic  # noqa: E402  (restricted loader for --load)
 
 
 def main():

@@ -207,9 +207,23 @@ class EncDecCTCModel(nn.Module):
             self._engine_key = key
         return self._engine
 
+    def _frontend_hip_supported(self):
+        """The HIP front-end kernels are built for the QuartzNet / Jasper preprocessor (quartznet_15x5.yaml:30-41):
+        n_fft 512, hop 160, a 320-tap window, per-feature normalisation, log(x + 2^-24), power spectrum.  Any other
+        featurizer configuration runs the host module on the GPU tensors instead - the same module calibration used -
+        rather than silently producing different features (a shorter window would even be read out of bounds)."""
+        f = self.preprocessor.featurizer
+        return (f.n_fft == 512 and f.hop_length == 160 and f.win_length == 320 and f.window.numel() == 320
+                and f.fb.dim() == 3 and f.fb.shape[2] == 257 and f.normalize == 'per_feature' and bool(f.log)
+                and f.log_zero_guard_type == 'add' and not isinstance(f.log_zero_guard_value, str)
+                and float(f.log_zero_guard_value) == 2.0 ** -24 and float(f.mag_power) == 2.0 and f.preemph is not None
+                and f.pad_value == 0 and isinstance(f.pad_to, int) and f.pad_to >= 0)
+
     def _frontend_hip(self, signal, length):
         from qasr import engine as qengine
         f = self.preprocessor.featurizer
+        if not self._frontend_hip_supported():
+            return self.preprocessor(input_signal=signal, length=length)
         if f.dither > 0:
             signal = signal + f.dither * torch.randn_like(signal)
         return qengine.frontend_mel(signal.float().contiguous(), length, f.fb[0].contiguous(), f.window.contiguous(),

@@ -79,3 +79,38 @@ def test_two_rank_gloo_broadcast_shard_gather(golden_dir):
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res == {0: 'ok', 1: 'ok'}, res
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _run_bench(*argv, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py'), *argv], capture_output=True, text=True, env=e,
+                          timeout=240)
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`python bench.py --gpus N` with no launcher must produce N ranks by itself (the driver runs it that way): the parent
+    spawns the ranks, relays rank 0's JSON line, and the census all-reduce sees every rank.  --dry-run keeps the engine
+    (GPU-only) out of it; the process group, blob broadcast and per-step token gather are the ones bench.py times."""
+    r = _run_bench('--gpus', '2', '--dry-run', '--steps', '3', '--warmup', '1')
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['n_ranks_seen'] == 2 and d['dry_run'] is True
+
+
+def test_bench_launcher_fails_loudly_without_enough_gpus():
+    """More ranks requested than GPUs visible: non-zero exit and no JSON line, never a silent one-GPU measurement."""
+    torch_gpus = torch.cuda.device_count()
+    r = _run_bench('--gpus', str(torch_gpus + 2), '--steps', '1')
+    assert r.returncode != 0
+    assert not any(ln.startswith('{') for ln in r.stdout.splitlines())
+    assert 'GPU(s) visible' in r.stderr
+
+
+def test_bench_rejects_mismatched_world_size():
+    r = _run_bench('--gpus', '2', '--dry-run', env=dict(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
+    assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)

@@ -204,3 +204,64 @@ def test_nemo_archive_round_trip(tmp_path):
         assert k1 == k2 and torch.equal(v1, v2)
     with pytest.raises(FileNotFoundError):
         EncDecCTCModel.from_pretrained('QuartzNet15x5Base-En')
+
+
+def test_load_reads_reference_pickle_and_rejects_code(tmp_path):
+    """`--load` must read what the reference's synthesize.py writes - pickle.dump([x.cpu() ...]) (synthesize.py:103-104) -
+    and nothing that would run code from the file."""
+    import pickle
+
+    from qasr.calib_io import load_synthetic
+    g = torch.Generator().manual_seed(0)
+    batches = [torch.rand(4, 64, 50, generator=g) - 0.5, torch.rand(4, 64, 50, generator=g)[:, :, ::2]]   # one non-contiguous
+    p = tmp_path / 'synthetic.pkl'
+    with open(p, 'wb') as f:
+        pickle.dump([x.cpu() for x in batches], f)
+    got = load_synthetic(str(p))
+    assert len(got) == 2 and all(torch.equal(a, b) for a, b in zip(got, batches))
+    pt = tmp_path / 'synthetic.pt'
+    torch.save(batches, pt)
+    assert all(torch.equal(a, b) for a, b in zip(load_synthetic(str(pt)), batches))
+    npz = tmp_path / 'synthetic.npz'
+    np.savez(npz, a=batches[0].numpy(), b=batches[1].numpy())
+    assert all(torch.equal(a, b) for a, b in zip(load_synthetic(str(npz)), batches))
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ('echo pwned > /dev/null',))
+    bad = tmp_path / 'evil.pkl'
+    with open(bad, 'wb') as f:
+        pickle.dump([batches[0], Evil()], f)
+    with pytest.raises(pickle.UnpicklingError, match='not allowed'):
+        load_synthetic(str(bad))
+    notlist = tmp_path / 'str.pkl'
+    with open(notlist, 'wb') as f:
+        pickle.dump(['text'], f)
+    with pytest.raises(ValueError):
+        load_synthetic(str(notlist))
+
+
+def test_mel_filterbank_matches_slaney_reference():
+    """FilterbankFeatures takes its matrix from librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax) (features.py:281-283:
+    Slaney scale, Slaney norm).  librosa is absent here; transformers' mel_filter_bank implements the same published
+    construction and is what the survey's reference run used as the stand-in - qasr.melbank equals it bit for bit."""
+    from transformers.audio_utils import mel_filter_bank
+
+    from qasr.melbank import mel_filterbank
+    for n_mels, fmax in ((64, 8000.0), (80, 8000.0), (64, 7600.0)):
+        want = mel_filter_bank(257, n_mels, 0.0, fmax, 16000, norm='slaney', mel_scale='slaney').T.astype(np.float32)
+        got = mel_filterbank(16000, 512, n_mels, 0, fmax)
+        assert got.shape == want.shape and np.array_equal(got, want), np.abs(got - want).max()
+
+
+def test_engine_frontend_guard_rejects_other_featurizers():
+    """The HIP front-end is built for the 20 ms hann / 10 ms hop / n_fft 512 preprocessor; any other featurizer
+    configuration must route to the host module (ctc_models._frontend_hip_supported), never to the kernels."""
+    base = configs.model_config('MiniQuartzNet')
+    assert EncDecCTCModel(base)._frontend_hip_supported()
+    for patch in (dict(window_size=0.025), dict(normalize='all_features'), dict(window_stride=0.02), dict(n_fft=1024),
+                  dict(log_zero_guard_value=1e-5), dict(mag_power=1.0)):
+        cfg = json.loads(json.dumps(base))
+        cfg['preprocessor'].update(patch)
+        assert not EncDecCTCModel(cfg)._frontend_hip_supported(), patch

@@ -26,9 +26,10 @@ def _gpu():
 
 
 def test_frontend_hip_matches_reference(golden_dir):
-    """qasr_frontend_mel vs FilterbankFeatures of the reference (fixture); float32, tolerance-based:
-    FFT butterfly order and reduction order differ from torch.stft / torch.matmul (<= 2e-3 on the normalised
-    log-mel scale, i.e. ~1e-3 of one quantisation step of the first-layer QuantAct)."""
+    """qasr_frontend_mel vs FilterbankFeatures of the reference (fixture), tolerance-based: <= 1e-4 absolute on the
+    normalised log-mel.  The spectrum is computed in float64 and rounded once; an exact spectrum
+    followed by the reference's float32 steps sits at 5.5e-5 max / 4e-7 mean from the fixture (the reference's own
+    float32 FFT rounding), which is what this kernel should reproduce."""
     from qasr import engine
     d = np.load(os.path.join(golden_dir, 'frontend.npz'))
     y, seq = engine.frontend_mel(torch.from_numpy(d['audio']).cuda(), torch.from_numpy(d['lens']).cuda(),
@@ -37,8 +38,8 @@ def test_frontend_hip_matches_reference(golden_dir):
     y = y.cpu().numpy()
     assert y.shape == d['feats'].shape
     err = np.abs(y - d['feats'])
-    assert err.max() < 2e-3, err.max()
-    assert err.mean() < 2e-5, err.mean()
+    assert err.max() <= 1e-4, err.max()
+    assert err.mean() < 2e-6, err.mean()
     for b, n in enumerate(d['seq_len']):
         assert np.all(y[b, :, n:] == 0)          # masked + pad_to frames are exactly zero
 
@@ -80,9 +81,9 @@ def test_model_engine_path_equals_host_path(name, wbit, abit, pct):
 
 def test_model_from_audio_full_quartznet():
     """Audio -> HIP front-end -> integer QuartzNet15x5 -> tokens, against host front-end + host modules.
-    The two front-ends differ by float rounding, so a few first-layer roundings may flip: tokens must agree
-    on >= 95 % of frames of this random-weight net, whose argmax margins are tiny (bit-exactness is defined
-    from identical features, SURVEY hard-part 6, and checked at the end of this test)."""
+    The two front-ends differ by float rounding (<= 1e-4 on the features), so a few first-layer roundings may flip:
+    tokens must agree on >= 99 % of frames of this random-weight net, whose argmax margins are tiny (bit-exactness is
+    defined from identical features, SURVEY hard-part 6, and checked at the end of this test)."""
     m = _prepared_model('QuartzNet15x5Base-En', seed=5, percentile=99.996, feat=64, frames=128)
     m.preprocessor.featurizer.dither = 0.0
     audio = torch.from_numpy(synth.make_audio(4, 32000, seed=3)).cuda()
@@ -95,7 +96,7 @@ def test_model_from_audio_full_quartznet():
     tok_host = m.decoder(encoder_output=e, encoder_output_scaling_factor=sf).argmax(-1)
     assert torch.equal(el, l)
     agree = (tok == tok_host).float().mean().item()
-    assert agree >= 0.95, agree
+    assert agree >= 0.99, agree
     # identical features -> identical tokens (the bit-exact contract)
     lp2, _, tok2 = m(processed_signal=feats, processed_signal_length=flen)
     assert torch.equal(tok2, tok_host)
