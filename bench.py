@@ -61,7 +61,6 @@ def parse_args(argv=None):
     ap.add_argument('--tile', type=int, default=0, choices=[0, 32, 64],
                     help='frames per work-group of the separable-layer kernels: 32 = lowest single-step latency, 64 = less '
                          'weight/halo traffic per frame but half the work-groups; 0 = 64 when more than one step is in flight')
-    ap.add_argument('--lean', action='store_true', help='lean k_sep2 (32-frame tiles, <= 128 VGPRs: two work-groups share a CU)')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel instead of replaying the captured hipGraph')
     ap.add_argument('--whole-utterance', action='store_true', help='use the k_utt kernels (one work-group per utterance)')
     ap.add_argument('--streams', type=int, default=int(os.environ.get('QASR_BENCH_STREAMS', 0)),
@@ -343,7 +342,7 @@ def run(args):
         """S steps in flight: per step in flight an engine (own arena), a HIP stream, its own audio batch and its own
         feature / length / token buffers (stable pointers: the forward replays as one hipGraph launch)."""
         engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance, wide_tiles=(tile == 64),
-                              graph=not args.no_graph, lean=(args.lean and S > 1)) for _ in range(S)]
+                              graph=not args.no_graph) for _ in range(S)]
         streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
         T_out = engs[0].out_frames(T_pad)
         audio = [torch.from_numpy(synth.make_audio(BATCH, SAMPLES, seed=100 + 16 * rank + k)).to(dev) for k in range(S)]

@@ -67,7 +67,7 @@ struct qasr_engine {
   std::vector<char> skip;              // per op: launched as part of the following op
   bool wide_tiles = false;             // k_sep with 64-frame tiles (throughput mode: bit 3 of `debug`, or QASR_WIDE_TILES=1)
   bool use_utt = false;                // whole-utterance kernels k_utt (bit 2 of `debug`, or QASR_UTT=1)
-  int sep_gen = 2;                     // 2: k_sep2 where it has the shape; 3: its lean form (bit 5 of `debug`); 1 (QASR_SEP_GEN=1): k_sep everywhere
+  int sep_gen = 2;                     // 2: k_sep2 where it has the shape; 1 (QASR_SEP_GEN=1): k_sep everywhere (A/B runs)
   std::vector<char> utt;               // per op: 0 = k_sep, 1 = k_utt plain, 2 = k_utt residual pair (rq32 + add32)
   int32_t* r32 = nullptr;              // scratch [B][max cout][Tp] of the residual pair
   // hipGraph replay (bit 4 of `debug`): the whole forward of one (shape, buffer set) is captured once and re-launched
@@ -315,8 +315,7 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
   e->debug = (debug & 1) != 0;
   e->fuse = getenv("QASR_NO_FUSE") == nullptr;
   e->legacy_pw = getenv("QASR_LEGACY_PW") != nullptr;
-  if (debug & 32) e->sep_gen = 3;                          // lean k_sep2 (32-frame tiles, two work-groups per CU)
-  if (const char* g = getenv("QASR_SEP_GEN")) e->sep_gen = atoi(g) >= 1 && atoi(g) <= 3 ? atoi(g) : 2;
+  if (const char* g = getenv("QASR_SEP_GEN")) e->sep_gen = atoi(g) == 1 ? 1 : 2;
   // whole-utterance kernels (k_utt) are opt-in: bit 2 of `debug` or QASR_UTT=1 (throughput experiments)
   e->use_utt = (debug & 4) != 0 || getenv("QASR_UTT") != nullptr;
   e->wide_tiles = (debug & 8) != 0 || getenv("QASR_WIDE_TILES") != nullptr;

@@ -11,15 +11,13 @@ extern template int launch_sep_inst<32, false>(hipStream_t, const SepP&);
 extern template int launch_sep_inst<32, true>(hipStream_t, const SepP&);
 extern template int launch_sep_inst<64, false>(hipStream_t, const SepP&);
 extern template int launch_sep_inst<64, true>(hipStream_t, const SepP&);
-extern template int launch_sep2_inst<32, false, false>(hipStream_t, const SepP&);
-extern template int launch_sep2_inst<32, true, false>(hipStream_t, const SepP&);
-extern template int launch_sep2_inst<64, false, false>(hipStream_t, const SepP&);
-extern template int launch_sep2_inst<64, true, false>(hipStream_t, const SepP&);
-extern template int launch_sep2_inst<32, false, true>(hipStream_t, const SepP&);
-extern template int launch_sep2_inst<32, true, true>(hipStream_t, const SepP&);
+extern template int launch_sep2_inst<32, false>(hipStream_t, const SepP&);
+extern template int launch_sep2_inst<32, true>(hipStream_t, const SepP&);
+extern template int launch_sep2_inst<64, false>(hipStream_t, const SepP&);
+extern template int launch_sep2_inst<64, true>(hipStream_t, const SepP&);
 
 // k_sep2 takes the stride-1 separable layers it is built for (sep2_shape_ok) unless the engine was told to stay on k_sep
-bool sep2_takes(const SepP& p) { return p.gen >= 2 && sep2_shape_ok(p); }   // gen 3: lean form (32-frame tiles)
+bool sep2_takes(const SepP& p) { return p.gen == 2 && sep2_shape_ok(p); }
 
 bool sep_supported(int K, int dilation) {
   if (dilation == 2) return K == 87 || K == 15;
@@ -30,8 +28,8 @@ bool sep_supported(int K, int dilation) {
 void sep_kernel_label(const SepP& p, char* buf, size_t cap) {
   const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
   if (sep2_takes(p)) {
-    snprintf(buf, cap, "k_sep2<%d, %d, %d, %d, %s, %d, %s>", p.K, p.cin_pad >> 7, (p.e.flags & QASR_F_RESADD) ? p.panes[0].cin_pad >> 7 : 0,
-             (p.e.cout + 255) / 256, dbg ? "true" : "false", (p.gen == 3 || p.tile != 64) ? 32 : 64, p.gen == 3 ? "true" : "false");
+    snprintf(buf, cap, "k_sep2<%d, %d, %d, %d, %s, %d>", p.K, p.cin_pad >> 7, (p.e.flags & QASR_F_RESADD) ? p.panes[0].cin_pad >> 7 : 0,
+             (p.e.cout + 255) / 256, dbg ? "true" : "false", p.tile == 64 ? 64 : 32);
     return;
   }
   snprintf(buf, cap, "k_sep<%d, %d, %d, %s, %d>", p.K, p.K > 0 ? p.dilation : 1, sep_epilogue_class(p), dbg ? "true" : "false",
@@ -48,9 +46,8 @@ int sep_tile_for(const SepP& p) {
 int launch_sep(hipStream_t s, const SepP& p) {
   const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
   if (sep2_takes(p)) {
-    if (p.gen == 3) return dbg ? launch_sep2_inst<32, true, true>(s, p) : launch_sep2_inst<32, false, true>(s, p);
-    if (p.tile == 64) return dbg ? launch_sep2_inst<64, true, false>(s, p) : launch_sep2_inst<64, false, false>(s, p);
-    return dbg ? launch_sep2_inst<32, true, false>(s, p) : launch_sep2_inst<32, false, false>(s, p);
+    if (p.tile == 64) return dbg ? launch_sep2_inst<64, true>(s, p) : launch_sep2_inst<64, false>(s, p);
+    return dbg ? launch_sep2_inst<32, true>(s, p) : launch_sep2_inst<32, false>(s, p);
   }
   if (!sep_supported(p.K, p.K > 0 ? p.dilation : 1)) return QASR_ERR_UNSUPPORTED;
   if (sep_tile_for(p) == 64) return dbg ? launch_sep_inst<64, true>(s, p) : launch_sep_inst<64, false>(s, p);

@@ -49,7 +49,7 @@ typedef v4i __attribute__((address_space(3))) lds_v4i;
 #endif
 #define SEP2_CH 256                     /* channels per staged window chunk */
 
-template <int K, int TT, bool LEAN = false>
+template <int K, int TT>
 struct Sep2Geo {
   static constexpr int PAD = K / 2;
   static constexpr int HALO = (PAD + 15) / 16 * 16;      // staged halo (16-B granular)
@@ -65,8 +65,7 @@ struct Sep2Geo {
   static constexpr int WLEN = TT + 2 * HALO;             // staged bytes per window row
   // LDS row pitch: the lanes of one LDS access group read S-byte runs of 4 (b128) / 8 (b64) different rows; an odd
   // multiple of 4 S bytes puts those rows on disjoint banks (a power-of-two pitch made every read 4-way conflicted)
-  // (the lean build keeps the dense pitch: two work-groups must fit one CU's LDS)
-  static constexpr int WP = LEAN ? WLEN : ((WLEN + 4 * S - 1) / (4 * S) | 1) * (4 * S);
+  static constexpr int WP = ((WLEN + 4 * S - 1) / (4 * S) | 1) * (4 * S);
   static constexpr int NPG = WLEN / 16;                  // 16-B granules per row
   static constexpr int NPT = (SEP2_CH * NPG + SEP2_NT - 1) / SEP2_NT;   // window granules per thread and chunk
   static constexpr int KP4 = (K + 3) / 4;
@@ -146,37 +145,6 @@ __device__ __forceinline__ void sep2_gemm(v16i (&acc)[MT], v4i (&wf)[16], const 
   }
 }
 
-// Lean form (two work-groups per CU, <= 128 VGPRs): no resident slab - the weight groups of ALL GEMMs of the kernel form
-// one flat sequence streamed through three buffers of 4 K steps; group FB + g sits in buffer (FB + g) % 3, and the
-// group two ahead is requested (src(j): fragment pointer of flat group j) before each group's MFMAs.  Latency is hidden
-// by the second work-group of the CU rather than by prefetch depth.
-template <int MT, int N, int FB, int TOTAL, class Src>
-__device__ __forceinline__ void sep2_gemm_stream(v16i (&acc)[MT], v4i (&wf)[12], const lds_u8* img_lane, int mt_stride, Src&& src) {
-  v4i a[2][MT][2];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) a[0][mt][i] = sep2_a_frag(img_lane + mt * mt_stride, i);
-#pragma unroll
-  for (int q = 0; q < 2 * N; ++q) {
-    constexpr int dummy = 0;
-    (void)dummy;
-    const int g = q >> 1;
-    if (!(q & 1) && FB + g + 2 < TOTAL) sep2_load_wg(&wf[4 * ((FB + g + 2) % 3)], src(FB + g + 2));
-    if (q + 1 < 2 * N) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[(q + 1) & 1][mt][i] = sep2_a_frag(img_lane + mt * mt_stride, 2 * (q + 1) + i);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q & 1][mt][i], wf[4 * ((FB + g) % 3) + 2 * (q & 1) + i], acc[mt], 0, 0, 0);
-  }
-}
-
 // per-lane (= per output channel, MFMA C layout: channel = lane & 31) parameters of one 256-channel pass
 struct Sep2PassP {
   int bias, pbias;
@@ -188,9 +156,9 @@ struct Sep2PassP {
 // K taps, NG groups of 128 input channels (cin_pad = 128 NG), NGP groups of the residual 1x1 conv (0: no res_act),
 // NP passes of 256 output channels - all compile-time: the whole kernel is straight-line code, which is what lets the
 // compiler count its s_waitcnt vmcnt(N) exactly instead of draining every prefetch at each join
-template <int K, int NG, int NGP, int NP, bool DBG, int TT, bool LEAN>
-__global__ void __launch_bounds__(SEP2_NT, LEAN ? 4 : SEP2_WPE) k_sep2(SepP p) {
-  using G = Sep2Geo<K, TT, LEAN>;
+template <int K, int NG, int NGP, int NP, bool DBG, int TT>
+__global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
+  using G = Sep2Geo<K, TT>;
   constexpr bool RES = NGP > 0;
   constexpr int MT = TT / 32;
   constexpr int NU = G::NU, S = G::S, NS = G::NS;
@@ -227,15 +195,9 @@ __global__ void __launch_bounds__(SEP2_NT, LEAN ? 4 : SEP2_WPE) k_sep2(SepP p) {
   // the depthwise math (pf<CH>(lo, hi)).
   const unsigned flip = p.x_unsigned ? 0x80808080u : 0u;
   constexpr int NRT = RES ? (TT * PCIN_PAD / 16) / SEP2_NT : 0;
-  v4i pc[G::NPT], pt[G::NTT], rr[NRT > 0 ? NRT : 1], wf[LEAN ? 12 : 16];
-  constexpr int NGT = NG + NGP, NFLAT = NP * NGT;            // lean: flat sequence of weight groups (pass-major: main, residual)
+  v4i pc[G::NPT], pt[G::NTT], rr[NRT > 0 ? NRT : 1], wf[16];
   const int co_l = 32 * wave + (lane & 31);                  // row inside a 256-channel pass
   const v4i* const w0 = w_frag(p.w, CIN_PAD, co_l, 0);
-  auto wsrc = [&](int j) -> const v4i* {                     // fragment pointer of flat weight group j (lean)
-    const int ps = j / NGT, r = j - ps * NGT;
-    if (r < NG) return w_frag(p.w, CIN_PAD, 256 * ps + co_l, 0) + 256 * r;
-    return w_frag(p.panes[0].w, PCIN_PAD, 256 * ps + co_l, 0) + 256 * (r - NG);
-  };
   auto ld_win = [&](int c0, int i) {                         // window granule i of this thread (coalesced 16-B granules)
     const int pi = tid + SEP2_NT * i;
     const int row = pi / G::NPG, col = pi - row * G::NPG;
@@ -258,19 +220,13 @@ __global__ void __launch_bounds__(SEP2_NT, LEAN ? 4 : SEP2_WPE) k_sep2(SepP p) {
   auto pf = [&](auto chc, int lo, int hi) {
     constexpr int CH = decltype(chc)::value;
     constexpr int n_win = CH + 1 < NCHUNK ? G::NPT : 0, n_tap = CH + 1 < NCHUNK ? G::NTT : 0;
-    constexpr int n_res = CH + 1 == NCHUNK ? NRT : 0;
-    // deep: the whole slab of pass 0 behind chunk 0; lean: the first two flat groups behind the last chunk
-    constexpr int n_slab = LEAN ? (CH + 1 == NCHUNK ? 8 : 0) : (CH == 0 ? 4 * NG : 0);
+    constexpr int n_res = CH + 1 == NCHUNK ? NRT : 0, n_slab = CH == 0 ? 4 * NG : 0;
 #pragma unroll
     for (int i = lo; i < hi; ++i) {
       if (i < n_win) ld_win(SEP2_CH * (CH + 1), i);
       else if (i < n_win + n_tap) ld_tap(SEP2_CH * (CH + 1), i - n_win);
       else if (i < n_win + n_tap + n_res) ld_res(i - n_win - n_tap);
-      else if (i < n_win + n_tap + n_res + n_slab) {
-        const int j = i - n_win - n_tap - n_res;
-        if constexpr (LEAN) wf[j] = wsrc(j >> 2)[64 * (j & 3)];
-        else wf[j] = w0[64 * j];
-      }
+      else if (i < n_win + n_tap + n_res + n_slab) wf[i - n_win - n_tap - n_res] = w0[64 * (i - n_win - n_tap - n_res)];
     }
   };
   auto commit = [&](int c0) {                                // registers -> LDS
@@ -404,8 +360,7 @@ __global__ void __launch_bounds__(SEP2_NT, LEAN ? 4 : SEP2_WPE) k_sep2(SepP p) {
   auto chunk = [&](auto chc) {
     constexpr int CH = decltype(chc)::value;
     constexpr int c0 = SEP2_CH * CH;
-    constexpr int NPF = (CH + 1 < NCHUNK ? G::NPT + G::NTT : 0) + (CH + 1 == NCHUNK ? NRT : 0) +
-                        (LEAN ? (CH + 1 == NCHUNK ? 8 : 0) : (CH == 0 ? 4 * NG : 0));
+    constexpr int NPF = (CH + 1 < NCHUNK ? G::NPT + G::NTT : 0) + (CH + 1 == NCHUNK ? NRT : 0) + (CH == 0 ? 4 * NG : 0);
     constexpr int Q = (NPF + 5) / 6;                         // six issue points per chunk
     if (CH) __syncthreads();                                 // previous chunk's window and taps fully consumed
     if (stamp) {                                             // diagnostics: when did this wave's window / taps land?
@@ -422,24 +377,16 @@ __global__ void __launch_bounds__(SEP2_NT, LEAN ? 4 : SEP2_WPE) k_sep2(SepP p) {
       for (int gi = 0; gi < 2 * NCHUNK; ++gi) asm volatile("" : "+v"(dbias[gi]), "+v"(dM[gi]));
     }
     STAMP2();
-    if constexpr (LEAN) {                                    // one operand set at a time (register budget)
-      DwIn in;
-      dw_read(in, 0);
-      dw_math(in, c0, 0, dbias[2 * CH], dM[2 * CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
-      dw_read(in, 1);
-      dw_math(in, c0, 1, dbias[2 * CH + 1], dM[2 * CH + 1], [&](int k) { pf(chc, Q * (3 + k), Q * (4 + k)); });
-    } else {                                                 // both groups' LDS operands in flight before the first MFMA
-      DwIn inA, inB;
-      dw_read(inA, 0);
-      dw_read(inB, 1);
-      dw_math(inA, c0, 0, dbias[2 * CH], dM[2 * CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
-      dw_math(inB, c0, 1, dbias[2 * CH + 1], dM[2 * CH + 1], [&](int k) { pf(chc, Q * (3 + k), Q * (4 + k)); });
-    }
+    DwIn inA, inB;
+    dw_read(inA, 0);
+    dw_read(inB, 1);
+    dw_math(inA, c0, 0, dbias[2 * CH], dM[2 * CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
+    dw_math(inB, c0, 1, dbias[2 * CH + 1], dM[2 * CH + 1], [&](int k) { pf(chc, Q * (3 + k), Q * (4 + k)); });
     STAMP2();
   };
   chunk(std::integral_constant<int, 0>{});
   if constexpr (NCHUNK > 1) chunk(std::integral_constant<int, 1>{});
-  static_assert(NCHUNK <= 2 && NP <= 2, "more than 512 input / output channels");
+  static_assert(NCHUNK <= 2, "more than 512 input channels");
   __syncthreads();                                           // Xd complete, window dead
   if constexpr (RES) {                                       // residual A image [PCIN_PAD][32] per 32-frame tile
     const unsigned rflip = p.panes[0].x_unsigned ? 0x80808080u : 0u;
@@ -479,14 +426,8 @@ __global__ void __launch_bounds__(SEP2_NT, LEAN ? 4 : SEP2_WPE) k_sep2(SepP p) {
       for (int r = 0; r < 16; ++r) acc[mt][r] = pp.bias;
     // once multiplied, a slab group is re-requested: with the residual conv's group (beyond its K depth: the next
     // pass's main group); after the residual GEMM with the next pass's main groups that are still missing
-    if constexpr (LEAN) {
-      if (ps == 0) sep2_gemm_stream<MT, NG, 0, NFLAT>(acc, wf, xd_lane, CIN_PAD * 32, wsrc);
-      else sep2_gemm_stream<MT, NG, NGT, NFLAT>(acc, wf, xd_lane, CIN_PAD * 32, wsrc);
-    } else if constexpr (RES) {
-      sep2_gemm<MT, NG, (NGP < NG ? NGP : NG)>(acc, wf, xd_lane, CIN_PAD * 32, wpane, wnext);
-    } else {
-      sep2_gemm<MT, NG, 0>(acc, wf, xd_lane, CIN_PAD * 32, nullptr, wnext);
-    }
+    if constexpr (RES) sep2_gemm<MT, NG, (NGP < NG ? NGP : NG)>(acc, wf, xd_lane, CIN_PAD * 32, wpane, wnext);
+    else sep2_gemm<MT, NG, 0>(acc, wf, xd_lane, CIN_PAD * 32, nullptr, wnext);
     STAMP2();
     // accumulator hooks, then masked frames (t >= lim): an accumulator of 0 requantises to 0 for every consumer
     // (lo <= 0 <= hi) and through res_act
@@ -548,12 +489,7 @@ __global__ void __launch_bounds__(SEP2_NT, LEAN ? 4 : SEP2_WPE) k_sep2(SepP p) {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accp[mt][r] = pp.pbias;
-      if constexpr (LEAN) {
-        if (ps == 0) sep2_gemm_stream<MT, NGP, NG, NFLAT>(accp, wf, xr_lane, PCIN_PAD * 32, wsrc);
-        else sep2_gemm_stream<MT, NGP, NGT + NG, NFLAT>(accp, wf, xr_lane, PCIN_PAD * 32, wsrc);
-      } else {
-        sep2_gemm<MT, NGP, (NGP < NG ? NGP : NG)>(accp, wf, xr_lane, PCIN_PAD * 32, wnext, nullptr);
-      }
+      sep2_gemm<MT, NGP, (NGP < NG ? NGP : NG)>(accp, wf, xr_lane, PCIN_PAD * 32, wnext, nullptr);
       STAMP2();
       finish(accp, pdbg, pp.sbp);
 #pragma unroll
@@ -600,9 +536,9 @@ __global__ void __launch_bounds__(SEP2_NT, LEAN ? 4 : SEP2_WPE) k_sep2(SepP p) {
 #undef STAMP2
 }
 
-template <int K, int TT, bool LEAN>
+template <int K, int TT>
 static inline size_t sep2_smem_bytes(const SepP& p) {
-  using G = Sep2Geo<K, TT, LEAN>;
+  using G = Sep2Geo<K, TT>;
   const size_t xd = (size_t)TT * p.cin_pad;
   size_t ws = (size_t)std::min(SEP2_CH, p.cin) * G::WP + 64;
   if (p.n_panes == 1) ws = std::max(ws, (size_t)TT * p.panes[0].cin_pad);
@@ -640,29 +576,29 @@ static inline bool sep2_shape_ok(const SepP& p) {
   return false;
 }
 
-template <int K, int NG, int NGP, int NP, bool DBG, int TT, bool LEAN>
+template <int K, int NG, int NGP, int NP, bool DBG, int TT>
 static int launch_sep2_v(hipStream_t s, const SepP& p) {
-  const size_t smem = sep2_smem_bytes<K, TT, LEAN>(p);
-  if (smem > (LEAN ? 80 : 160) * 1024 || p.e.B < 1 || p.e.Tp % TT || !p.x || !p.w || !p.wdw2) return QASR_ERR_ARG;
+  const size_t smem = sep2_smem_bytes<K, TT>(p);
+  if (smem > 160 * 1024 || p.e.B < 1 || p.e.Tp % TT || !p.x || !p.w || !p.wdw2) return QASR_ERR_ARG;
   static int attr_dev = -1;                                  // the attribute is per device
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (attr_dev != dev) {
-    (void)hipFuncSetAttribute((const void*)k_sep2<K, NG, NGP, NP, DBG, TT, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_sep2<K, NG, NGP, NP, DBG, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_dev = dev;
   }
   SepP q = p;
   q.prof = g_prof;
-  hipLaunchKernelGGL((k_sep2<K, NG, NGP, NP, DBG, TT, LEAN>), dim3(p.e.B, p.e.Tp / TT, 1), dim3(SEP2_NT), smem, s, q);
+  hipLaunchKernelGGL((k_sep2<K, NG, NGP, NP, DBG, TT>), dim3(p.e.B, p.e.Tp / TT, 1), dim3(SEP2_NT), smem, s, q);
   return QASR_OK;
 }
 
-// all instantiations of one (tile, debug, lean) triple; QASR_ERR_UNSUPPORTED for a shape without one
-template <int TT, bool DBG, bool LEAN>
+// all instantiations of one (tile, debug) pair; QASR_ERR_UNSUPPORTED for a shape without one
+template <int TT, bool DBG>
 int launch_sep2_inst(hipStream_t s, const SepP& p) {
   const int ng = p.cin_pad >> 7, ngp = (p.e.flags & QASR_F_RESADD) ? (p.panes[0].cin_pad >> 7) : 0, np = (p.e.cout + 255) / 256;
 #define SEP2_LAUNCH(K_, NG_, NGP_, NP_) \
-  if (p.K == K_ && ng == NG_ && ngp == NGP_ && np == NP_) return launch_sep2_v<K_, NG_, NGP_, NP_, DBG, TT, LEAN>(s, p);
+  if (p.K == K_ && ng == NG_ && ngp == NGP_ && np == NP_) return launch_sep2_v<K_, NG_, NGP_, NP_, DBG, TT>(s, p);
   SEP2_INSTANCES(SEP2_LAUNCH)
 #undef SEP2_LAUNCH
   return QASR_ERR_UNSUPPORTED;

@@ -2,5 +2,5 @@
 #include "qasr_sep2_impl.h"
 
 namespace qasr {
-template int launch_sep2_inst<32, false, false>(hipStream_t, const SepP&);
+template int launch_sep2_inst<32, false>(hipStream_t, const SepP&);
 }  // namespace qasr

@@ -80,7 +80,7 @@ class Engine:
     """One packed model on one GPU (qasr_engine_*)."""
 
     def __init__(self, blob: bytes, device=0, debug=False, timing=False, whole_utterance=False, wide_tiles=False,
-                 graph=False, lean=False):
+                 graph=False):
         lib = load_library()
         if not torch.cuda.is_available():
             raise QasrError('no GPU: the integer engine needs an MI355X (there is no CPU fallback)')
@@ -89,7 +89,7 @@ class Engine:
         self._blob = blob
         self._h = C.c_void_p()
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
-        _check(lib.qasr_engine_create(C.cast(buf, C.c_void_p), len(blob), device, int(bool(debug)) | (2 if timing else 0) | (4 if whole_utterance else 0) | (8 if wide_tiles else 0) | (16 if graph else 0) | (32 if lean else 0),
+        _check(lib.qasr_engine_create(C.cast(buf, C.c_void_p), len(blob), device, int(bool(debug)) | (2 if timing else 0) | (4 if whole_utterance else 0) | (8 if wide_tiles else 0) | (16 if graph else 0),
                                       C.byref(self._h)),
                'qasr_engine_create')
         self.debug = debug
