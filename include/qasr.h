@@ -212,6 +212,45 @@ int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t
 int qasr_requant(void* stream, const int32_t* acc, const double* m, const float* sb, int exact_z, int relu,
                  int B, int c, int Tp, int lo, int hi, int8_t* out);
 
+/* One fused time-channel-separable layer exactly as the engine launches it (k_sep2 / k_sep): depthwise QuantConv1d
+ * (K taps, stride 1, 'same' padding) -> QuantAct requant -> 1x1 QuantConv1d [-> residual 1x1 QuantConv1d + res_act] ->
+ * ReLU -> the consumers' QuantAct requant (jasper.py:569-600,664-687; quant_modules.py:186-190,301-309).  Every pointer
+ * is a device pointer in the blob's layouts (see qasr_op_desc): the parity tests drive the production kernels through
+ * this entry with operands of their own making (accumulators beyond 2^22, rounding ties, ragged lengths).
+ * K == 0: no depthwise stage (`x` feeds the 1x1 conv).  gen: 2 = k_sep2 where it has the shape, 1 = k_sep.
+ * tile: 32 or 64 frames per work-group.  `label` (optional) receives the kernel instantiation that ran. */
+typedef struct qasr_sep_layer_args {
+  int32_t B, T, Tp, cin, cout, K, dilation, tile, gen;
+  uint32_t flags;              /* QASR_F_RELU | MASK_OUT | EXACT_Z | RESADD */
+  const int8_t* x;             /* [B][cin][Tp] depthwise input (1x1 input when K == 0) */
+  int32_t x_unsigned, dw_lo, dw_hi, n_outs;
+  const int8_t* wdw;           /* s8 [cin][kpad4] */
+  const int8_t* wdw2;          /* s8 [cin][kpad4 + 32]: taps behind 8 zero bytes */
+  const int32_t* bias_dw;      /* i32 [cin_pad128] (128 * sum(w) for u8 inputs) */
+  const double* m_dw;          /* f64 [cin_pad128] */
+  const int8_t* w;             /* s8 cout_pad128 x cin_pad128, MFMA fragment order */
+  const int32_t* bias;         /* i32 [cout_pad128] */
+  const float* sb;             /* f32 [cout_pad128] (EXACT_Z) */
+  const double* m_main;        /* f64 [cout_pad128] (RESADD) */
+  const int32_t* lens;         /* i32 [B] valid frames */
+  const int8_t* rx;            /* RESADD: residual conv input [B][rcin][Tp] */
+  const int8_t* rw;            /*         its weights, fragment order */
+  const int32_t* rbias;
+  const double* rm;
+  const float* rsb;
+  int32_t rcin, r_unsigned, qlo, qhi;
+  struct {
+    void* ptr;                 /* i8 [B][cout][Tp] */
+    const double* mtab;        /* mode 1 */
+    double m;                  /* mode 0 */
+    int32_t lo, hi, mode, pad_;
+  } outs[QASR_MAX_OUTS];
+  int32_t* dw_acc;             /* optional hooks: i32 [B][cin][Tp], [B][cout][Tp], [B][cout][Tp] */
+  int32_t* acc;
+  int32_t* racc;
+} qasr_sep_layer_args;
+int qasr_sep_layer(void* stream, const qasr_sep_layer_args* a, char* label, size_t label_cap);
+
 /* Diagnostics: when set to a device buffer of 32 int64, work-group (1,0,0) of every k_sep launch writes s_memtime
  * stamps at its phase boundaries (slot 31 = number of stamps); NULL (default) disables. */
 int qasr_debug_prof(void* dev_buf);

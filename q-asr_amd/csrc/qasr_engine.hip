@@ -792,6 +792,73 @@ int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t
   return QASR_OK;
 }
 
+int qasr_sep_layer(void* stream, const qasr_sep_layer_args* a, char* label, size_t label_cap) {
+  if (!a || !a->x || !a->w || !a->bias || !a->lens || a->B < 1 || a->cin < 1 || a->cout < 1 || a->Tp % 64 || a->T > a->Tp ||
+      a->n_outs < 0 || a->n_outs > QASR_MAX_OUTS || (a->tile != 32 && a->tile != 64))
+    return fail(QASR_ERR_ARG, "sep_layer: bad arguments");
+  SepP p{};
+  p.x = a->x;
+  p.wdw = a->wdw;
+  p.wdw2 = a->wdw2;
+  p.bias_dw = a->bias_dw;
+  p.m_dw = a->m_dw;
+  p.dw_acc_dbg = a->dw_acc;
+  p.dw_lo = a->dw_lo;
+  p.dw_hi = a->dw_hi;
+  p.K = a->K;
+  p.x_unsigned = a->K > 0 ? a->x_unsigned : 0;
+  p.pw_unsigned = a->K > 0 ? 0 : a->x_unsigned;
+  p.dilation = a->K > 0 ? a->dilation : 1;
+  p.tile = a->tile;
+  p.gen = a->gen;
+  p.w = a->w;
+  p.bias = a->bias;
+  p.cin = a->cin;
+  p.cin_pad = rup(a->cin, 128);
+  if (a->flags & QASR_F_RESADD) {
+    if (!a->rx || !a->rw || !a->rbias || !a->rm || !a->m_main || a->rcin < 1) return fail(QASR_ERR_ARG, "sep_layer: residual operands missing");
+    p.n_panes = 1;
+    PaneP& d = p.panes[0];
+    d.x = a->rx;
+    d.w = a->rw;
+    d.bias = a->rbias;
+    d.m = a->rm;
+    d.sb = a->rsb;
+    d.acc_dbg = a->racc;
+    d.cin = a->rcin;
+    d.cin_pad = rup(a->rcin, 128);
+    d.x_unsigned = a->r_unsigned;
+  }
+  EpiP& e = p.e;
+  e.n_outs = a->n_outs;
+  for (int j = 0; j < a->n_outs; ++j) {
+    e.outs[j].ptr = a->outs[j].ptr;
+    e.outs[j].mtab = a->outs[j].mtab;
+    e.outs[j].m = a->outs[j].m;
+    e.outs[j].lo = a->outs[j].lo;
+    e.outs[j].hi = a->outs[j].hi;
+    e.outs[j].mode = a->outs[j].mode;
+    if (!a->outs[j].ptr || (a->outs[j].mode == 1 && !a->outs[j].mtab)) return fail(QASR_ERR_ARG, "sep_layer: consumer %d incomplete", j);
+  }
+  e.flags = a->flags & (QASR_F_RELU | QASR_F_MASK_OUT | QASR_F_EXACT_Z | QASR_F_RESADD);
+  if ((e.flags & QASR_F_EXACT_Z) && !a->sb) return fail(QASR_ERR_ARG, "sep_layer: EXACT_Z needs the conv output scales");
+  e.sb = a->sb;
+  e.m_main = a->m_main;
+  e.lens = a->lens;
+  e.acc_dbg = a->acc;
+  e.qlo = a->qlo;
+  e.qhi = a->qhi;
+  e.T = a->T;
+  e.Tp = a->Tp;
+  e.cout = a->cout;
+  e.B = a->B;
+  if (label && label_cap >= 8) sep_kernel_label(p, label, label_cap);
+  int rc = launch_sep((hipStream_t)stream, p);
+  if (rc) return fail(rc, "sep_layer: no kernel instantiation for K=%d dilation=%d (or bad launch shape)", p.K, p.dilation);
+  HIPCHK(hipGetLastError());
+  return QASR_OK;
+}
+
 int qasr_requant(void* stream, const int32_t* acc, const double* m, const float* sb, int exact_z, int relu, int B, int c,
                  int Tp, int lo, int hi, int8_t* out) {
   if (!acc || !m || !out || (exact_z && !sb)) return fail(QASR_ERR_ARG, "requant: bad arguments");

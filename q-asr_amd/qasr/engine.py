@@ -13,10 +13,26 @@ SYMBOLS = ['qasr_engine_create', 'qasr_engine_destroy', 'qasr_engine_forward', '
            'qasr_engine_num_ops', 'qasr_engine_read_acc', 'qasr_engine_read_tensor', 'qasr_engine_last_op_ms',
            'qasr_engine_time_ops', 'qasr_engine_run_op', 'qasr_engine_op_label',
            'qasr_frontend_mel', 'qasr_frontend_frames', 'qasr_frontend_workspace_bytes', 'qasr_pw_conv_acc',
-           'qasr_dw_conv_acc', 'qasr_requant', 'qasr_quantile2', 'qasr_quantile_workspace_bytes', 'qasr_debug_prof',
+           'qasr_dw_conv_acc', 'qasr_requant', 'qasr_sep_layer', 'qasr_quantile2', 'qasr_quantile_workspace_bytes', 'qasr_debug_prof',
            'qasr_last_error', 'qasr_version']
 
 _lib = None
+
+
+class _SepOut(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('mtab', C.c_void_p), ('m', C.c_double), ('lo', C.c_int32), ('hi', C.c_int32),
+                ('mode', C.c_int32), ('pad_', C.c_int32)]
+
+
+class SepLayerArgs(C.Structure):
+    """qasr_sep_layer_args (include/qasr.h)."""
+    _fields_ = ([(n, C.c_int32) for n in ('B', 'T', 'Tp', 'cin', 'cout', 'K', 'dilation', 'tile', 'gen')] +
+                [('flags', C.c_uint32), ('x', C.c_void_p)] +
+                [(n, C.c_int32) for n in ('x_unsigned', 'dw_lo', 'dw_hi', 'n_outs')] +
+                [(n, C.c_void_p) for n in ('wdw', 'wdw2', 'bias_dw', 'm_dw', 'w', 'bias', 'sb', 'm_main', 'lens', 'rx', 'rw',
+                                           'rbias', 'rm', 'rsb')] +
+                [(n, C.c_int32) for n in ('rcin', 'r_unsigned', 'qlo', 'qhi')] +
+                [('outs', _SepOut * 3), ('dw_acc', C.c_void_p), ('acc', C.c_void_p), ('racc', C.c_void_p)])
 
 
 class QasrError(RuntimeError):
@@ -53,6 +69,7 @@ def load_library():
     lib.qasr_dw_conv_acc.argtypes = [vp, vp, i32, vp] + [i32] * 11 + [vp]
     lib.qasr_requant.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.qasr_debug_prof.argtypes = [vp]
+    lib.qasr_sep_layer.argtypes = [vp, C.POINTER(SepLayerArgs), C.c_char_p, sz]
     lib.qasr_quantile2.argtypes = [vp, vp, sz, C.c_float, C.c_float, vp, vp, sz]
     lib.qasr_quantile_workspace_bytes.argtypes = []
     lib.qasr_quantile_workspace_bytes.restype = sz
@@ -232,6 +249,121 @@ def requant(acc: torch.Tensor, M: torch.Tensor, lo, hi, sb=None, exact_z=False, 
     _check(lib.qasr_requant(_stream_ptr(), _ptr(a), _ptr(Md), _ptr(sbd), int(exact_z), int(relu), B, Cc, Tp, lo, hi,
                             _ptr(out)), 'qasr_requant')
     return out[:, :, :T]
+
+
+def sep_layer(x, lens, wpw, bias, outs, wdw=None, m_dw=None, dw_range=(-128, 127), x_unsigned=False, dilation=1,
+              flags=0, sb=None, res=None, tile=32, gen=2, hooks=True):
+    """One fused separable layer through qasr_sep_layer (the production kernels with caller-made operands).
+
+    x            int8 / uint8 [B, cin, T] (cuda)      lens  valid frames per utterance
+    wdw          int8 [cin, K] depthwise taps (None: the layer is a bare 1x1 conv), m_dw f64 [cin], dw_range (lo, hi)
+    wpw, bias    int8 [cout, cin], int32 [cout]       sb f32 [cout] conv output scales (QASR_F_EXACT_Z)
+    outs         list of dicts(mode, lo, hi, M=f64 [cout] (mode 1) or m=float (mode 0))
+    res          None or dict(x [B, rcin, T] (uint8 / int8), w int8 [cout, rcin], bias int32 [cout], m f64 [cout],
+                 sb f32 [cout], m_main f64 [cout], qlo, qhi)   -> QASR_F_RESADD
+    Biases are the natural ones: the +128 sum(W) correction of u8 inputs is folded here, as pack.py does.
+    Returns dict(outs=[int8 [B, cout, T]...], dw_acc, acc, racc (int32, None without hooks), label)."""
+    from .pack import F_RESADD, fragment_order
+    lib = load_library()
+    dev = x.device
+    B, cin, T = x.shape
+    cout = wpw.shape[0]
+    Tp, cinp, coutp = _rup(T, 64), _rup(cin, 128), _rup(cout, 128)
+    keep = []
+
+    def dv(t, dtype=None):
+        t = torch.as_tensor(t)
+        t = (t.to(dtype) if dtype is not None else t).to(dev).contiguous()
+        keep.append(t)
+        return t
+
+    def padded_x(t):
+        p = torch.zeros(t.shape[0], t.shape[1], Tp, dtype=torch.int8, device=dev)
+        p[:, :, :T] = t.view(torch.int8) if t.dtype == torch.uint8 else t
+        keep.append(p)
+        return p
+
+    def frag(w, rows, cols):
+        wp = torch.zeros(rows, cols, dtype=torch.int8)
+        wp[:w.shape[0], :w.shape[1]] = torch.as_tensor(w).cpu()
+        return dv(torch.from_numpy(fragment_order(wp.numpy())))
+
+    def padvec(v, n, dtype, fill=0):
+        o = torch.full((n,), fill, dtype=dtype)
+        o[:len(v)] = torch.as_tensor(v).to(dtype).cpu()
+        return dv(o)
+
+    a = SepLayerArgs()
+    a.B, a.T, a.Tp, a.cin, a.cout, a.dilation, a.tile, a.gen = B, T, Tp, cin, cout, dilation, tile, gen
+    a.flags = flags | (F_RESADD if res is not None else 0)
+    a.x = padded_x(x).data_ptr()
+    a.x_unsigned = int(x_unsigned)
+    a.lens = dv(lens, torch.int32).data_ptr()
+    if wdw is not None:
+        wdw = torch.as_tensor(wdw).cpu().to(torch.int8)
+        K = wdw.shape[1]
+        kp = _rup(K, 4)
+        w1 = torch.zeros(cin, kp, dtype=torch.int8)
+        w1[:, :K] = wdw
+        w2 = torch.zeros(cin, kp + 32, dtype=torch.int8)
+        w2[:, 8:8 + K] = wdw
+        a.K = K
+        a.wdw, a.wdw2 = dv(w1).data_ptr(), dv(torch.cat([w2.view(-1), torch.zeros(64, dtype=torch.int8)])).data_ptr()
+        bdw = 128 * wdw.to(torch.int32).sum(1) if x_unsigned else torch.zeros(cin, dtype=torch.int32)
+        a.bias_dw = padvec(bdw, cinp, torch.int32).data_ptr()
+        a.m_dw = padvec(m_dw, cinp, torch.float64).data_ptr()
+        a.dw_lo, a.dw_hi = dw_range
+        pw_bias = torch.as_tensor(bias).to(torch.int32).cpu()
+    else:
+        a.K = 0
+        pw_bias = torch.as_tensor(bias).to(torch.int32).cpu()
+        if x_unsigned:
+            pw_bias = pw_bias + 128 * torch.as_tensor(wpw).cpu().to(torch.int32).sum(1)
+    a.w = frag(wpw, coutp, cinp).data_ptr()
+    a.bias = padvec(pw_bias, coutp, torch.int32).data_ptr()
+    if sb is not None:
+        a.sb = padvec(sb, coutp, torch.float32, 1.0).data_ptr()
+    if res is not None:
+        rcin = res['x'].shape[1]
+        a.rx = padded_x(res['x']).data_ptr()
+        a.r_unsigned = int(res['x'].dtype == torch.uint8)
+        a.rcin = rcin
+        a.rw = frag(res['w'], coutp, _rup(rcin, 128)).data_ptr()
+        rb = torch.as_tensor(res['bias']).to(torch.int32).cpu()
+        if a.r_unsigned:
+            rb = rb + 128 * torch.as_tensor(res['w']).cpu().to(torch.int32).sum(1)
+        a.rbias = padvec(rb, coutp, torch.int32).data_ptr()
+        a.rm = padvec(res['m'], coutp, torch.float64).data_ptr()
+        if res.get('sb') is not None:
+            a.rsb = padvec(res['sb'], coutp, torch.float32, 1.0).data_ptr()
+        a.m_main = padvec(res['m_main'], coutp, torch.float64).data_ptr()
+        a.qlo, a.qhi = res['qlo'], res['qhi']
+    a.n_outs = len(outs)
+    out_t = []
+    for j, o in enumerate(outs):
+        t = torch.zeros(B, cout, Tp, dtype=torch.int8, device=dev)
+        out_t.append(t)
+        a.outs[j].ptr = t.data_ptr()
+        a.outs[j].mode, a.outs[j].lo, a.outs[j].hi = o['mode'], o['lo'], o['hi']
+        if o['mode'] == 1:
+            a.outs[j].mtab = padvec(o['M'], coutp, torch.float64).data_ptr()
+        elif o['mode'] == 0:
+            a.outs[j].m = float(o['m'])
+    hk = {}
+    if hooks:
+        if wdw is not None:
+            hk['dw_acc'] = torch.zeros(B, cin, Tp, dtype=torch.int32, device=dev)
+            a.dw_acc = hk['dw_acc'].data_ptr()
+        hk['acc'] = torch.zeros(B, cout, Tp, dtype=torch.int32, device=dev)
+        a.acc = hk['acc'].data_ptr()
+        if res is not None:
+            hk['racc'] = torch.zeros(B, cout, Tp, dtype=torch.int32, device=dev)
+            a.racc = hk['racc'].data_ptr()
+    label = C.create_string_buffer(96)
+    _check(lib.qasr_sep_layer(_stream_ptr(), C.byref(a), label, 96), 'qasr_sep_layer')
+    torch.cuda.synchronize()
+    return dict(outs=[t[:, :, :T] for t in out_t], label=label.value.decode(),
+                **{k: (hk[k][:, :, :T] if k in hk else None) for k in ('dw_acc', 'acc', 'racc')})
 
 
 def frontend_mel(audio: torch.Tensor, lens: torch.Tensor, fb: torch.Tensor, window: torch.Tensor, preemph=0.97,

@@ -276,6 +276,26 @@ class Packer:
                 self.tensors[op['out_tensor']]['producer'] = oi
 
     @staticmethod
+    def _exact_z_matters(op):
+        """QASR_F_EXACT_Z asks the kernels for fixedpoint_mul's float32 round trip z = rint(fl32(fl32(acc) s) / s)
+        (quant_utils.py:187) wherever |acc| may exceed 2^22 - 1, because only below that bound z == acc is a theorem.
+        Above it |z - acc| <= 2, i.e. the product z M moves by at most 2 M.  When even the smallest multiplier of every
+        consumer already drives such an accumulator past the clamp range, (2^22 - 3) M - 1/2 >= max(|lo|, |hi|), both z and
+        acc requantise to the same saturated code and the round trip cannot change a result: the flag is dropped
+        (ordinary layers: M ~ 1e-3, i.e. 2^22 M ~ 4000 against a range of 128 / 255).  res_act sums two unbounded terms
+        and raw / identity outputs keep the accumulator itself, so those ops keep the flag."""
+        if op['flags'] & F_RESADD:
+            return True
+        outs = op.get('outs', [])
+        if not outs or any(o['mode'] != 1 for o in outs):
+            return True
+        for o in outs:
+            m_min = float(_t(o['M']).min())
+            if (Z_EXACT_LIMIT - 2) * m_min - 0.5 < max(abs(o['lo']), abs(o['hi'])):
+                return True
+        return False
+
+    @staticmethod
     def _wide_requant(op):
         """True when some |acc * M| of the op may reach 2^30: k_sep2 takes the rounded product from the low mantissa
         word (exact below 2^31), k_sep clamps in the double domain and takes such ops instead."""
@@ -342,6 +362,8 @@ class Packer:
             w_off = bias_off = m_off = sb_off = 0
             if kind in (OP_DW, OP_PW, OP_DENSE) and self._wide_requant(op):
                 op['flags'] |= F_WIDE_RQ
+            if kind in (OP_DW, OP_PW, OP_DENSE) and (op['flags'] & F_EXACT_Z) and not self._exact_z_matters(op):
+                op['flags'] &= ~F_EXACT_Z
             if kind in (OP_DW, OP_PW, OP_DENSE):
                 w_off = self._pack_weights(kind, op['wi'], bool(op['flags'] & F_TAPMAJOR))
                 bias_off = self._vec(op['bint'].to(torch.int32), cp, np.int32)

@@ -33,9 +33,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_packer(tmp_path):
     probe = tmp_path / 'probe.c'
-    probe.write_text('#include <stdio.h>\n#include "qasr.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    probe.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "qasr.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                      'sizeof(qasr_blob_header),sizeof(qasr_tensor_desc),sizeof(qasr_op_desc),sizeof(qasr_out),'
-                     'sizeof(qasr_pane),sizeof(qasr_domain_desc));return 0;}\n')
+                     'sizeof(qasr_pane),sizeof(qasr_domain_desc),sizeof(qasr_sep_layer_args),'
+                     'offsetof(qasr_sep_layer_args, outs),offsetof(qasr_sep_layer_args, racc));return 0;}\n')
     exe = tmp_path / 'probe'
     subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(probe), '-o', str(exe)], check=True)
     sizes = list(map(int, subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()))
@@ -44,6 +45,9 @@ def test_struct_sizes_match_packer(tmp_path):
     assert sizes[3] == struct.calcsize('<iiiIQd') and sizes[4] == struct.calcsize('<iIQQQQ')
     assert sizes[2] == struct.calcsize('<IIiIIIIIIIQQQQiifI') + 3 * sizes[3] + 12 * sizes[4]
     assert sizes[5] == struct.calcsize('<iIIII3I')
+    from qasr import engine                                   # the ctypes mirror of the operator-level argument block
+    assert sizes[6] == ctypes.sizeof(engine.SepLayerArgs)
+    assert sizes[7] == engine.SepLayerArgs.outs.offset and sizes[8] == engine.SepLayerArgs.racc.offset
 
 
 def test_engine_create_rejects_garbage_without_touching_gpu():

@@ -425,3 +425,92 @@ def test_quartznet_t500_every_accumulator(eng, oracle_quartznet_t500, family):
         assert np.array_equal(tokens.cpu().numpy()[b, :n], want['tokens'][b, :n])
         np.testing.assert_allclose(logp.cpu().numpy()[b, :n], want['log_probs'][b, :n], rtol=1e-4, atol=5e-5)
     e.close()
+
+
+# ---------------------------------------------------------------------------------- fused layer, operator level
+def _sep_case(rng, B, T, cin, cout, K, x_unsigned, res, n_outs, big=False):
+    """Operands of one separable layer with realistic magnitudes; `big` pushes accumulators past 2^22 in a few channels."""
+    lens = np.array([T] + list(rng.integers(1, T + 1, B - 1)))
+    x = rng.integers(0 if x_unsigned else -128, 256 if x_unsigned else 128, (B, cin, T))
+    x = np.where(np.arange(T)[None, None, :] < lens[:, None, None], x, 0)
+    wdw = rng.integers(-127, 127, (cin, K))
+    m_dw = 127.0 / (np.abs(wdw).sum(1) * (255 if x_unsigned else 128) * rng.uniform(0.2, 0.6, cin))
+    wpw = rng.integers(-127, 127, (cout, cin))
+    bias = rng.integers(-20000, 20000, cout)
+    sb = rng.uniform(1e-6, 3e-6, cout).astype(np.float32)
+    if big:                                                    # same-sign rows + a large bias: |acc| well past 2^22
+        wpw[:8] = np.abs(wpw[:8])
+        wpw[8:16] = -np.abs(wpw[8:16])
+        wdw[:] = np.abs(wdw)
+        m_dw = m_dw * 4                                        # the depthwise output saturates at +127 almost everywhere
+        bias[:8] += 3_000_000
+        bias[8:16] -= 3_000_000
+    outs = []
+    for j in range(n_outs):
+        hi = 255 if j % 2 == 0 else 127
+        lo = 0 if res is None else -hi - 1
+        outs.append(dict(mode=1, lo=lo, hi=hi, M=rng.uniform(2e-4, 2e-3, cout)))
+    r = None
+    if res:
+        rcin = res
+        rx = np.where(np.arange(T)[None, None, :] < lens[:, None, None], rng.integers(0, 256, (B, rcin, T)), 0)
+        r = dict(x=rx, w=rng.integers(-127, 127, (cout, rcin)), bias=rng.integers(-20000, 20000, cout),
+                 m=rng.uniform(2e-4, 2e-3, cout), sb=rng.uniform(1e-6, 3e-6, cout).astype(np.float32),
+                 m_main=rng.uniform(2e-4, 2e-3, cout), qlo=-128, qhi=127)
+        outs = [dict(mode=2, lo=0, hi=127)] + [dict(mode=0, lo=0, hi=255, m=float(rng.uniform(1.2, 2.0)))][: n_outs - 1]
+    return dict(x=x, lens=lens, wdw=wdw, m_dw=m_dw, wpw=wpw, bias=bias, sb=sb, outs=outs, res=r)
+
+
+SEP_SHAPES = [(33, 256, 256, 0), (39, 256, 256, 256), (51, 256, 512, 0), (51, 512, 512, 256), (51, 512, 512, 512),
+              (63, 512, 512, 0), (63, 512, 512, 512), (75, 512, 512, 0), (75, 512, 512, 512)]
+
+
+@pytest.mark.parametrize('gen,tile', [(2, 32), (2, 64), (1, 32), (1, 64)], ids=['k_sep2_32', 'k_sep2_64', 'k_sep_32', 'k_sep_64'])
+@pytest.mark.parametrize('K,cin,cout,rcin', SEP_SHAPES)
+def test_sep_layer_against_oracle(eng, gen, tile, K, cin, cout, rcin):
+    """The fused separable-layer kernels at operator level (qasr_sep_layer): every production tap count / channel shape of
+    QuartzNet15x5 at T = 250 and 301 (several time tiles, halos across tile borders, ragged lengths incl. 1 frame),
+    u8 depthwise input, one res_act case per shape, accumulators beyond 2^22 with QASR_F_EXACT_Z - depthwise accumulator,
+    1x1 accumulator, residual accumulator and every consumer's requantised output bit-exact against the numpy oracle."""
+    from qasr.pack import F_EXACT_Z, F_MASK_OUT, F_RELU
+    for T, big in ((250, False), (301, True)):
+        rng = np.random.default_rng(K * 1000 + T + cin + rcin)
+        c = _sep_case(rng, 3, T, cin, cout, K, True, rcin or None, 2, big=big)
+        want = O.sep_layer_ref(c['x'], c['lens'], c['wdw'], c['m_dw'], (-128, 127), c['wpw'], c['bias'], c['outs'], relu=True,
+                               mask_out=True, sb=c['sb'], exact_z=big, res=c['res'])
+        if big:
+            assert np.abs(want['acc']).max() >= 1 << 22           # the float32 round trip is really exercised
+        res = None
+        if c['res'] is not None:
+            res = dict(c['res'], x=torch.from_numpy(c['res']['x'].astype(np.uint8)).cuda())
+        got = eng.sep_layer(torch.from_numpy(c['x'].astype(np.uint8)).cuda(), c['lens'], c['wpw'], c['bias'], c['outs'],
+                            wdw=c['wdw'], m_dw=c['m_dw'], x_unsigned=True, flags=F_RELU | F_MASK_OUT | (F_EXACT_Z if big else 0),
+                            sb=c['sb'], res=res, tile=tile, gen=gen)
+        assert got['label'].startswith('k_sep2<' if gen == 2 else 'k_sep<'), got['label']
+        assert np.array_equal(got['dw_acc'].cpu().numpy(), want['dw_acc']), (got['label'], T, 'depthwise accumulator')
+        assert np.array_equal(got['acc'].cpu().numpy(), want['acc']), (got['label'], T, '1x1 accumulator')
+        if rcin:
+            assert np.array_equal(got['racc'].cpu().numpy(), want['racc']), (got['label'], T, 'residual accumulator')
+        for j, o in enumerate(c['outs']):
+            g = got['outs'][j].cpu().numpy()
+            g = g.view(np.uint8).astype(np.int64) if o['hi'] > 127 else g.astype(np.int64)
+            assert np.array_equal(g, want['outs'][j]), (got['label'], T, f'consumer {j}', int((g != want['outs'][j]).sum()))
+
+
+def test_sep_layer_dilated_and_bare_1x1(eng):
+    """The shapes that stay on k_sep: the dilated depthwise layer of block 16 (K = 87, dilation 2) and a bare 1x1 conv."""
+    from qasr.pack import F_MASK_OUT, F_RELU
+    rng = np.random.default_rng(87)
+    c = _sep_case(rng, 2, 250, 512, 512, 87, True, None, 1)
+    want = O.sep_layer_ref(c['x'], c['lens'], c['wdw'], c['m_dw'], (-128, 127), c['wpw'], c['bias'], c['outs'], dilation=2,
+                           relu=True, mask_out=True)
+    for tile in (32, 64):
+        got = eng.sep_layer(torch.from_numpy(c['x'].astype(np.uint8)).cuda(), c['lens'], c['wpw'], c['bias'], c['outs'],
+                            wdw=c['wdw'], m_dw=c['m_dw'], x_unsigned=True, dilation=2, flags=F_RELU | F_MASK_OUT, tile=tile)
+        assert np.array_equal(got['dw_acc'].cpu().numpy(), want['dw_acc']) and np.array_equal(got['acc'].cpu().numpy(), want['acc'])
+        assert np.array_equal(got['outs'][0].cpu().numpy().view(np.uint8).astype(np.int64), want['outs'][0])
+    want = O.sep_layer_ref(c['x'], c['lens'], None, None, None, c['wpw'], c['bias'], c['outs'], relu=True, mask_out=True)
+    got = eng.sep_layer(torch.from_numpy(c['x'].astype(np.uint8)).cuda(), c['lens'], c['wpw'], c['bias'], c['outs'],
+                        x_unsigned=True, flags=F_RELU | F_MASK_OUT)
+    assert np.array_equal(got['acc'].cpu().numpy(), want['acc'])
+    assert np.array_equal(got['outs'][0].cpu().numpy().view(np.uint8).astype(np.int64), want['outs'][0])
