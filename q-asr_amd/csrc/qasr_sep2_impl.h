@@ -248,10 +248,25 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
       if (16 * gi < G::TAPB) *(lds_v4i*)(Tl + 16 * gi) = pt[i];
     }
   };
+  // K == 0 (a bare 1x1 conv, e.g. block 17 of QuartzNet): no depthwise stage - the [channel][frame] tile of `x` IS the
+  // A image, a plain 16-byte-granule copy (x_unsigned bytes take the -128 flip on the way)
+  constexpr int NXT = K == 0 ? (TT * CIN_PAD / 16) / SEP2_NT : 1;
+  v4i xg[NXT];
+  if constexpr (K == 0) {
 #pragma unroll
-  for (int i = 0; i < G::NPT; ++i) ld_win(0, i);
+    for (int i = 0; i < NXT; ++i) {
+      const int gi = tid + SEP2_NT * i;
+      const int c = gi / (TT / 16), q = gi - c * (TT / 16);
+      xg[i] = *(const v4i*)(p.x + ((size_t)b * CIN_PAD + c) * eTp + t0 + 16 * q);
+    }
 #pragma unroll
-  for (int i = 0; i < G::NTT; ++i) ld_tap(0, i);
+    for (int j = 0; j < 4 * NG; ++j) wf[j] = w0[64 * j];       // the whole first slab right behind the tile
+  } else {
+#pragma unroll
+    for (int i = 0; i < G::NPT; ++i) ld_win(0, i);
+#pragma unroll
+    for (int i = 0; i < G::NTT; ++i) ld_tap(0, i);
+  }
   STAMP2();                                                  // requests of chunk 0 issued
 
   // per-group depthwise parameters of this lane's channels and the per-lane parameters of every GEMM pass: a handful
@@ -259,11 +274,13 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   const int cb = lane >> 2, jl = lane & 3;
   int dbias[2 * NCHUNK];
   double dM[2 * NCHUNK];
+  if constexpr (K > 0) {
 #pragma unroll
-  for (int gi = 0; gi < 2 * NCHUNK; ++gi) {
-    const int c = SEP2_CH * (gi >> 1) + 32 * wave + 16 * (gi & 1) + cb;
-    dbias[gi] = p.bias_dw[c];
-    dM[gi] = p.m_dw[c];
+    for (int gi = 0; gi < 2 * NCHUNK; ++gi) {
+      const int c = SEP2_CH * (gi >> 1) + 32 * wave + 16 * (gi & 1) + cb;
+      dbias[gi] = p.bias_dw[c];
+      dM[gi] = p.m_dw[c];
+    }
   }
   Sep2PassP pps[NP];
 #pragma unroll
@@ -384,8 +401,21 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
     dw_math(inB, c0, 1, dbias[2 * CH + 1], dM[2 * CH + 1], [&](int k) { pf(chc, Q * (3 + k), Q * (4 + k)); });
     STAMP2();
   };
-  chunk(std::integral_constant<int, 0>{});
-  if constexpr (NCHUNK > 1) chunk(std::integral_constant<int, 1>{});
+  if constexpr (K > 0) {
+    chunk(std::integral_constant<int, 0>{});
+    if constexpr (NCHUNK > 1) chunk(std::integral_constant<int, 1>{});
+  } else {
+    static_assert(K > 0 || !RES, "the bare 1x1 form has no residual variant");
+    const unsigned xflip = p.pw_unsigned ? 0x80808080u : 0u;
+#pragma unroll
+    for (int i = 0; i < NXT; ++i) {
+      const int gi = tid + SEP2_NT * i;
+      const int c = gi / (TT / 16), q = gi - c * (TT / 16);
+      v4i v = xg[i];
+      v[0] ^= xflip; v[1] ^= xflip; v[2] ^= xflip; v[3] ^= xflip;
+      *(lds_v4i*)(Xd + (q >> 1) * (CIN_PAD * 32) + c * 32 + 16 * (q & 1)) = v;
+    }
+  }
   static_assert(NCHUNK <= 2, "more than 512 input channels");
   __syncthreads();                                           // Xd complete, window dead
   if constexpr (RES) {                                       // residual A image [PCIN_PAD][32] per 32-frame tile
@@ -540,6 +570,7 @@ template <int K, int TT>
 static inline size_t sep2_smem_bytes(const SepP& p) {
   using G = Sep2Geo<K, TT>;
   const size_t xd = (size_t)TT * p.cin_pad;
+  if (K == 0) return xd;
   size_t ws = (size_t)std::min(SEP2_CH, p.cin) * G::WP + 64;
   if (p.n_panes == 1) ws = std::max(ws, (size_t)TT * p.panes[0].cin_pad);
   return xd + G::TAPB + 64 + ws;
@@ -549,12 +580,13 @@ static inline size_t sep2_smem_bytes(const SepP& p) {
 // X(K, NG, NGP, NP)  (NP = passes of 256 output channels)
 #define SEP2_INSTANCES(X) \
   X(33, 2, 0, 1) X(39, 2, 0, 1) X(51, 2, 0, 2) X(51, 4, 0, 2) X(63, 4, 0, 2) X(75, 4, 0, 2) \
-  X(33, 2, 2, 1) X(39, 2, 2, 1) X(51, 4, 2, 2) X(51, 4, 4, 2) X(63, 4, 4, 2) X(75, 4, 4, 2)
+  X(33, 2, 2, 1) X(39, 2, 2, 1) X(51, 4, 2, 2) X(51, 4, 4, 2) X(63, 4, 4, 2) X(75, 4, 4, 2) \
+  X(0, 4, 0, 4)
 
 // Shapes k_sep2 is built for; everything else stays on k_sep.
 static inline bool sep2_shape_ok(const SepP& p) {
   const EpiP& e = p.e;
-  if (p.K <= 0 || p.dilation != 1 || p.dense_k > 1 || p.cin_pad & 127 || e.cout > 512) return false;
+  if (p.K < 0 || p.dilation != 1 || p.dense_k > 1 || p.cin_pad & 127 || e.cout > 1024) return false;
   if (e.flags & (QASR_F_LOGITS | QASR_F_WIDE_RQ)) return false;
   if (e.n_outs < 1) return false;
   int ngp = 0;
@@ -579,7 +611,7 @@ static inline bool sep2_shape_ok(const SepP& p) {
 template <int K, int NG, int NGP, int NP, bool DBG, int TT>
 static int launch_sep2_v(hipStream_t s, const SepP& p) {
   const size_t smem = sep2_smem_bytes<K, TT>(p);
-  if (smem > 160 * 1024 || p.e.B < 1 || p.e.Tp % TT || !p.x || !p.w || !p.wdw2) return QASR_ERR_ARG;
+  if (smem > 160 * 1024 || p.e.B < 1 || p.e.Tp % TT || !p.x || !p.w || (K > 0 && !p.wdw2)) return QASR_ERR_ARG;
   static int attr_dev = -1;                                  // the attribute is per device
   int dev = 0;
   (void)hipGetDevice(&dev);

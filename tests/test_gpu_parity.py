@@ -514,3 +514,14 @@ def test_sep_layer_dilated_and_bare_1x1(eng):
                         x_unsigned=True, flags=F_RELU | F_MASK_OUT)
     assert np.array_equal(got['acc'].cpu().numpy(), want['acc'])
     assert np.array_equal(got['outs'][0].cpu().numpy().view(np.uint8).astype(np.int64), want['outs'][0])
+    # block 17 of QuartzNet (512 -> 1024, bare 1x1): k_sep2's K = 0 form, both tile sizes
+    wpw = rng.integers(-127, 127, (1024, 512))
+    bias = rng.integers(-20000, 20000, 1024)
+    outs = [dict(mode=1, lo=0, hi=127, M=rng.uniform(2e-4, 2e-3, 1024))]
+    want = O.sep_layer_ref(c['x'], c['lens'], None, None, None, wpw, bias, outs, relu=True, mask_out=False)
+    for tile in (32, 64):
+        got = eng.sep_layer(torch.from_numpy(c['x'].astype(np.uint8)).cuda(), c['lens'], wpw, bias, outs, x_unsigned=True,
+                            flags=F_RELU, tile=tile, gen=2)
+        assert got['label'].startswith('k_sep2<0, 4, 0, 4'), got['label']
+        assert np.array_equal(got['acc'].cpu().numpy(), want['acc'])
+        assert np.array_equal(got['outs'][0].cpu().numpy().astype(np.int64), want['outs'][0])
