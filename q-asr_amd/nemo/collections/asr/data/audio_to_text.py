@@ -1,8 +1,9 @@
 """Minimal evaluation data path: JSON-lines manifest -> 16-bit PCM WAV -> padded batch.
 Mirrors the behaviour inference.py relies on: AudioToCharDataset items (audio, audio_len, tokens, tokens_len),
 pad-collate with pad id 0 (nemo/collections/asr/data/audio_to_text.py:41-78,81-291), LibriSpeech manifest
-fields {audio_filepath, duration, text} (scripts/get_librispeech_data.py:105-120), ENCharParser-style
-normalisation (parts/parsers.py:101-145: lower-case, drop characters outside the vocabulary)."""
+fields {audio_filepath, duration, text} (scripts/get_librispeech_data.py:105-120), transcripts through
+parsers.make_parser(labels, 'en', unk_id=-1, blank_id=-1, do_normalize=...) as AudioToCharDataset builds it
+(audio_to_text.py:258-267: ENCharParser = cleaners.clean_text + per-character lookup)."""
 import json
 import re
 import wave
@@ -28,10 +29,10 @@ def read_wav(path, target_sr=16000):
 
 
 def normalize_text(text, vocabulary):
-    text = text.lower()
-    text = re.sub(r'\s+', ' ', text).strip()
-    allowed = set(vocabulary)
-    return ''.join(c for c in text if c in allowed)
+    """Normalised transcript as the reference's parser sees it (ENCharParser._normalize, parsers.py:136-145)."""
+    from nemo.collections.asr.parts import parsers
+    out = parsers.make_parser(labels=list(vocabulary), name='en', unk_id=-1, blank_id=-1, do_normalize=True)._normalize(text)
+    return '' if out is None else out
 
 
 class AudioToCharDataset(Dataset):

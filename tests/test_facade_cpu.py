@@ -265,3 +265,26 @@ def test_engine_frontend_guard_rejects_other_featurizers():
         cfg = json.loads(json.dumps(base))
         cfg['preprocessor'].update(patch)
         assert not EncDecCTCModel(cfg)._frontend_hip_supported(), patch
+
+
+def test_en_char_parser_normalisation():
+    """ENCharParser / cleaners.clean_text (parsers.py:101-145, cleaners.py:93-215): lower-casing, whitespace, numbers to
+    words, abbreviations, + & % replaced by words, other punctuation to spaces - expected strings worked out by hand from
+    the reference's regexes (inflect / unidecode are absent: their restatement is documented as unpinned)."""
+    from nemo.collections.asr.parts import parsers
+    vocab = list(" abcdefghijklmnopqrstuvwxyz'")
+    p = parsers.make_parser(labels=vocab, name='en', unk_id=-1, blank_id=-1, do_normalize=True)
+    cases = {
+        "HELLO   World": "hello world",
+        "Mr. Smith & Co. pay 20% + tax": "mister smith and company pay twenty percent plus tax",
+        "it's 1234 now": "it's one thousand two hundred and thirty four now",
+        "the 21st of Jan. at 7:30pm": "the twenty first of january at seven thirty pm",
+        "café, naïve -- déjà vu!": "cafe naive deja vu",
+        "pi is 3.14": "pi is three point one four",
+    }
+    for raw, want in cases.items():
+        assert p._normalize(raw) == want, (raw, p._normalize(raw))
+    ids = p("Don't stop")
+    assert ids == [vocab.index(c) for c in "don't stop"]
+    base = parsers.make_parser(labels=vocab, name='base', unk_id=-1, blank_id=-1)
+    assert base("A-b") == [vocab.index('a'), vocab.index('b')]          # unknown '-' -> unk_id == blank_id -> dropped
