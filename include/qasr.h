@@ -82,8 +82,12 @@ enum {
   QASR_F_RESADD = 1u << 4,      /* res_act: q = clamp(rq(main) + rq(pane) ...) sequentially over panes */
   QASR_F_TAPMAJOR = 1u << 5,    /* DENSE op (stride 1, 'same' padding): weights stored as one MFMA-fragment-ordered
                                    [cout_pad][cin_pad] matrix per tap; runs on the k_sep tile kernel */
-  QASR_F_WIDE_RQ = 1u << 6      /* some |acc * m| of this op may reach 2^30 (a QuantAct calibrated on near-silence): the
+  QASR_F_WIDE_RQ = 1u << 6,     /* some |acc * m| of this op may reach 2^30 (a QuantAct calibrated on near-silence): the
                                    requantisation must clamp in the double domain (k_sep), not on the low word (k_sep2) */
+  QASR_F_W6PACK = 1u << 7       /* weights of this op and of its panes are stored sub-byte (weight_bit <= 6): 4 two's-
+                                   complement 6-bit codes per 3 bytes (b0 = c0 | c1 << 6, b1 = c1 >> 2 | c2 << 4,
+                                   b2 = c2 >> 4 | c3 << 2), element order unchanged; DW ops then carry no zero-margined
+                                   tap array (m_off = 0).  qasr_engine_create expands them to int8 on the device */
 };
 
 #define QASR_MAX_PANES 12

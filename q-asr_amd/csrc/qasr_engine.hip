@@ -11,7 +11,34 @@
 
 #include "qasr_internal.h"
 
+#include <unordered_map>
+
 using namespace qasr;
+
+// ---- sub-byte weight storage (QASR_F_W6PACK): expansion to int8 at load time --------------------------------------
+// In-register unpack would cost ~28 VALU instructions per 16-byte MFMA fragment (120 cycles against the MFMA's 32), so
+// the packed form is what travels (file, RCCL broadcast) and the kernels keep reading int8 fragments.
+__global__ void __launch_bounds__(256) k_unpack6(const uint8_t* __restrict__ in, int8_t* __restrict__ out, size_t n_quads) {
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < n_quads; q += (size_t)gridDim.x * blockDim.x) {
+    const unsigned w = in[3 * q] | ((unsigned)in[3 * q + 1] << 8) | ((unsigned)in[3 * q + 2] << 16);
+    unsigned o = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = (int)((w >> (6 * i)) & 0x3f);
+      o |= (unsigned)(((c ^ 0x20) - 0x20) & 0xff) << (8 * i);      // sign-extend the 6-bit field
+    }
+    ((unsigned*)out)[q] = o;
+  }
+}
+// zero-margined tap rows of the MFMA depthwise stage: [c][kp + 32], taps behind 8 zero bytes (pack.py writes them
+// into byte-per-code blobs; sub-byte blobs derive them here)
+__global__ void __launch_bounds__(256) k_tap_rows(const int8_t* __restrict__ w, int8_t* __restrict__ out, int C, int K, int kp) {
+  const int ks = kp + 32;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)C * ks; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i / ks), j = (int)(i - (size_t)c * ks) - 8;
+    out[i] = (j >= 0 && j < K) ? w[(size_t)c * kp + j] : (int8_t)0;
+  }
+}
 
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...) {
@@ -46,6 +73,8 @@ struct qasr_engine {
   bool timing = false;                 // per-op HIP events (qasr_engine_last_op_ms)
   std::vector<uint8_t> blob;           // host copy
   uint8_t* dblob = nullptr;            // device copy
+  int8_t* dexp = nullptr;              // QASR_F_W6PACK: int8 expansion of every sub-byte weight array (+ derived tap rows)
+  std::unordered_map<uint64_t, const int8_t*> wexp, wexp2;   // blob data offset -> expanded array / tap rows
   qasr_blob_header h{};
   const qasr_tensor_desc* tdesc = nullptr;
   const qasr_op_desc* ops = nullptr;
@@ -81,6 +110,12 @@ struct qasr_engine {
 template <class T>
 static const T* dev_at(const qasr_engine* e, uint64_t off) {
   return off ? reinterpret_cast<const T*>(e->dblob + e->h.data_off + off) : nullptr;
+}
+// int8 weight array at blob offset `off`: the blob bytes, or their load-time expansion for sub-byte blobs
+static const int8_t* dev_w(const qasr_engine* e, uint64_t off) {
+  if (!off) return nullptr;
+  auto it = e->wexp.find(off);
+  return it != e->wexp.end() ? it->second : dev_at<int8_t>(e, off);
 }
 
 static int conv_out_len(int len, const qasr_domain_desc& d) {
@@ -275,7 +310,7 @@ static void fill_panes(const qasr_engine* e, int oi, const qasr_op_desc& op, Pan
     PaneP& d = panes[k];
     const TensorRT& t = e->tens[s.in];
     d.x = (const int8_t*)t.ptr;
-    d.w = dev_at<int8_t>(e, s.w_off);
+    d.w = dev_w(e, s.w_off);
     d.bias = dev_at<int32_t>(e, s.bias_off);
     d.m = dev_at<double>(e, s.m_off);
     d.sb = dev_at<float>(e, s.sb_off);
@@ -338,6 +373,55 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
     delete e;
     return fail(QASR_ERR_HIP, "blob upload failed");
   }
+  // sub-byte blobs: expand every packed weight array (and derive the depthwise tap rows) once, on the device
+  {
+    struct Job { uint64_t off; size_t packed, expanded; int C, K, kp; };
+    std::vector<Job> jobs;
+    size_t total = 0;
+    auto add = [&](uint64_t off, size_t expanded, int C = 0, int K = 0, int kp = 0) {
+      if (!off || e->wexp.count(off)) return;
+      e->wexp[off] = nullptr;
+      jobs.push_back({off, expanded / 4 * 3, expanded, C, K, kp});
+      total += (expanded + 255) / 256 * 256;
+      if (C) total += ((size_t)C * (kp + 32) + 64 + 255) / 256 * 256;
+    };
+    for (uint32_t i = 0; i < h.n_ops; ++i) {
+      const qasr_op_desc& op = e->ops[i];
+      if (!(op.flags & QASR_F_W6PACK)) continue;
+      const size_t cp = rup((int)op.cout, 128), cinp = rup((int)op.cin, 128);
+      if (op.kind == QASR_OP_DW) add(op.w_off, (size_t)op.cout * rup((int)op.kernel, 4), (int)op.cout, (int)op.kernel, rup((int)op.kernel, 4));
+      else add(op.w_off, cp * cinp * (op.kind == QASR_OP_DENSE ? op.kernel : 1));
+      for (uint32_t k = 0; k < op.n_panes; ++k) add(op.panes[k].w_off, cp * (size_t)rup((int)op.panes[k].cin, 128));
+    }
+    if (!jobs.empty()) {
+      if (hipMalloc((void**)&e->dexp, total) != hipSuccess) {
+        qasr_engine_destroy(e);
+        return fail(QASR_ERR_HIP, "weight expansion buffer (%zu bytes)", total);
+      }
+      size_t pos = 0;
+      for (const Job& j : jobs) {
+        if (h.data_off + j.off + j.packed > n) {
+          qasr_engine_destroy(e);
+          return fail(QASR_ERR_BLOB, "packed weight array out of range");
+        }
+        int8_t* dst = e->dexp + pos;
+        pos += (j.expanded + 255) / 256 * 256;
+        hipLaunchKernelGGL(k_unpack6, dim3(1024), dim3(256), 0, 0, e->dblob + h.data_off + j.off, dst, j.expanded / 4);
+        e->wexp[j.off] = dst;
+        if (j.C) {
+          int8_t* rows = e->dexp + pos;
+          pos += ((size_t)j.C * (j.kp + 32) + 64 + 255) / 256 * 256;
+          (void)hipMemsetAsync(rows, 0, (size_t)j.C * (j.kp + 32) + 64, 0);
+          hipLaunchKernelGGL(k_tap_rows, dim3(256), dim3(256), 0, 0, dst, rows, j.C, j.K, j.kp);
+          e->wexp2[j.off] = rows;
+        }
+      }
+      if (hipDeviceSynchronize() != hipSuccess) {
+        qasr_engine_destroy(e);
+        return fail(QASR_ERR_HIP, "weight expansion failed");
+      }
+    }
+  }
   *out = e;
   return QASR_OK;
 }
@@ -349,6 +433,7 @@ void qasr_engine_destroy(qasr_engine* e) {
   free_plan(e);
   for (auto v : e->ev) (void)hipEventDestroy(v);
   if (e->dblob) (void)hipFree(e->dblob);
+  if (e->dexp) (void)hipFree(e->dexp);
   delete e;
 }
 
@@ -367,7 +452,7 @@ int qasr_engine_out_frames(const qasr_engine* e, int T) {
 static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
   const qasr_op_desc& op = e->ops[oi];
   const TensorRT& tin = e->tens[op.in];
-  p.w = dev_at<int8_t>(e, op.w_off);
+  p.w = dev_w(e, op.w_off);
   p.bias = dev_at<int32_t>(e, op.bias_off);
   p.cin = (int)op.cin;
   p.cin_pad = rup(p.cin, 128);
@@ -381,8 +466,11 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
     const qasr_op_desc& d = e->ops[di];
     const TensorRT& din = e->tens[d.in];
     p.x = (const int8_t*)din.ptr;
-    p.wdw = dev_at<int8_t>(e, d.w_off);
-    p.wdw2 = dev_at<int8_t>(e, d.m_off);                  // DW ops carry their zero-margined tap array in m_off
+    p.wdw = dev_w(e, d.w_off);
+    {                                                       // zero-margined tap rows: in the blob (m_off), or derived on load
+      auto it = e->wexp2.find(d.w_off);
+      p.wdw2 = it != e->wexp2.end() ? it->second : dev_at<int8_t>(e, d.m_off);
+    }
     p.bias_dw = dev_at<int32_t>(e, d.bias_off);
     p.m_dw = dev_at<double>(e, d.outs[0].m_off);
     p.dw_acc_dbg = (e->debug && !e->acc_dbg[di].empty()) ? e->acc_dbg[di][0] : nullptr;
@@ -435,7 +523,7 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
     case QASR_OP_DW: {
       DwP p{};
       p.x = (const int8_t*)tin.ptr;
-      p.w = dev_at<int8_t>(e, op.w_off);
+      p.w = dev_w(e, op.w_off);
       p.bias = dev_at<int32_t>(e, op.bias_off);
       p.C = (int)op.cin;
       p.K = (int)op.kernel;
@@ -488,7 +576,7 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
       }
       PwP p{};
       p.x = (const int8_t*)tin.ptr;
-      p.w = dev_at<int8_t>(e, op.w_off);
+      p.w = dev_w(e, op.w_off);
       p.bias = dev_at<int32_t>(e, op.bias_off);
       p.cin = (int)op.cin;
       p.cin_pad = rup(p.cin, 128);
@@ -509,7 +597,7 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
       }
       DenseP p{};
       p.x = (const int8_t*)tin.ptr;
-      p.w = dev_at<int8_t>(e, op.w_off);
+      p.w = dev_w(e, op.w_off);
       p.bias = dev_at<int32_t>(e, op.bias_off);
       p.cin = (int)op.cin;
       p.cin_pad = rup(p.cin, 128);

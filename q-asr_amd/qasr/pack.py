@@ -24,7 +24,7 @@ from .topology import ModelCfg, conv_plan
 
 MAGIC, VERSION = 0x52534151, 6
 OP_QUANT_IN, OP_DW, OP_PW, OP_DENSE, OP_LOGSOFTMAX, OP_REQUANT = range(6)
-F_RELU, F_MASK_OUT, F_EXACT_Z, F_LOGITS, F_RESADD, F_TAPMAJOR, F_WIDE_RQ = 1, 2, 4, 8, 16, 32, 64
+F_RELU, F_MASK_OUT, F_EXACT_Z, F_LOGITS, F_RESADD, F_TAPMAJOR, F_WIDE_RQ, F_W6PACK = 1, 2, 4, 8, 16, 32, 64, 128
 DT_S8, DT_U8, DT_F32, DT_I32 = range(4)
 MAX_PANES, MAX_OUTS = 12, 3
 COUT_ALIGN, CIN_ALIGN = 128, 128
@@ -40,6 +40,28 @@ def fragment_order(w: np.ndarray) -> np.ndarray:
     assert cp % 32 == 0 and cinp % 32 == 0
     v = w.reshape(cp // 32, 32, cinp // 32, 2, 16)          # [tile, r, ks, h, j]
     return np.ascontiguousarray(v.transpose(0, 2, 3, 1, 4)).reshape(-1)   # [tile, ks, h, r, j]
+
+
+def pack6(a: np.ndarray) -> np.ndarray:
+    """Sub-byte weight storage (BASELINE config 3): int8 codes in [-32, 31] (quant_utils.py:57-79 at 6 bits gives
+    [-31, 30]) -> 4 codes per 3 bytes, two's-complement 6-bit fields, little end first:
+    b0 = c0 | c1 << 6,  b1 = c1 >> 2 | c2 << 4,  b2 = c2 >> 4 | c3 << 2.  The element order (e.g. MFMA fragment order) is
+    kept; the engine expands the arrays back to int8 on the device when it loads the blob (qasr_engine_create)."""
+    c = np.ascontiguousarray(a).reshape(-1)
+    assert c.dtype == np.int8 and c.size % 4 == 0 and c.min() >= -32 and c.max() <= 31
+    u = (c.astype(np.int16) & 0x3f).astype(np.uint32).reshape(-1, 4)
+    word = u[:, 0] | (u[:, 1] << 6) | (u[:, 2] << 12) | (u[:, 3] << 18)
+    out = np.empty((word.size, 3), np.uint8)
+    out[:, 0], out[:, 1], out[:, 2] = word & 0xff, (word >> 8) & 0xff, (word >> 16) & 0xff
+    return out.reshape(-1)
+
+
+def unpack6(b: np.ndarray) -> np.ndarray:
+    """Inverse of pack6 (host restatement of the device expansion, for the tests)."""
+    t = np.ascontiguousarray(b).reshape(-1, 3).astype(np.uint32)
+    word = t[:, 0] | (t[:, 1] << 8) | (t[:, 2] << 16)
+    c = np.stack([(word >> (6 * i)) & 0x3f for i in range(4)], axis=1).astype(np.int16)
+    return ((c ^ 0x20) - 0x20).astype(np.int8).reshape(-1)
 
 
 def _t(a):
@@ -89,6 +111,10 @@ class Packer:
         off = len(self.data)
         self.data += np.ascontiguousarray(arr).tobytes()
         return off                   # relative to data section; rebased in serialise()
+
+    def _put_w(self, arr: np.ndarray) -> int:
+        """int8 weight array: stored sub-byte (pack6) when the model's weights have <= 6 bits."""
+        return self._put(pack6(arr) if self.wbit <= 6 else arr)
 
     def _tensor(self, channels, dtype, domain, producer):
         self.tensors.append(dict(channels=channels, dtype=dtype, domain=domain, producer=producer, last_use=-1))
@@ -333,16 +359,16 @@ class Packer:
             kp = _rup(k, 4)
             w = torch.zeros(cout, kp, dtype=torch.int8)
             w[:, :k] = wi[:, 0, :].to(torch.int8)
-            return self._put(w.numpy())
+            return self._put_w(w.numpy())
         cin, k = wi.shape[1], wi.shape[2]
         cinp = _rup(cin, CIN_ALIGN)
         w = torch.zeros(cp, k, cinp, dtype=torch.int8)
         w[:cout, :, :cin] = wi.permute(0, 2, 1).to(torch.int8)
         if kind == OP_PW:
-            return self._put(fragment_order(w[:, 0, :].numpy()))
+            return self._put_w(fragment_order(w[:, 0, :].numpy()))
         if tap_major:                                        # one fragment-ordered [cout_pad][cin_pad] matrix per tap
-            return self._put(np.concatenate([fragment_order(np.ascontiguousarray(w[:, t, :].numpy())) for t in range(k)]))
-        return self._put(w.numpy())
+            return self._put_w(np.concatenate([fragment_order(np.ascontiguousarray(w[:, t, :].numpy())) for t in range(k)]))
+        return self._put_w(w.numpy())
 
     def _vec(self, t, rows, dtype, fill=0):
         a = np.full(rows, fill, dtype=dtype)
@@ -364,12 +390,16 @@ class Packer:
                 op['flags'] |= F_WIDE_RQ
             if kind in (OP_DW, OP_PW, OP_DENSE) and (op['flags'] & F_EXACT_Z) and not self._exact_z_matters(op):
                 op['flags'] &= ~F_EXACT_Z
+            if kind in (OP_DW, OP_PW, OP_DENSE) and self.wbit <= 6:
+                op['flags'] |= F_W6PACK                      # weights (and panes' weights) are pack6 arrays
             if kind in (OP_DW, OP_PW, OP_DENSE):
                 w_off = self._pack_weights(kind, op['wi'], bool(op['flags'] & F_TAPMAJOR))
                 bias_off = self._vec(op['bint'].to(torch.int32), cp, np.int32)
                 sb_off = self._vec(op['s_b'], cp, np.float32, 1.0)
                 if op['flags'] & F_RESADD:
                     m_off = self._vec(Q.requant_multiplier(op['s_b'], op['S']), cp, np.float64, 0.0)
+                elif kind == OP_DW and self.wbit <= 6:
+                    m_off = 0                                # sub-byte blobs: the engine derives the zero-margined rows on load
                 elif kind == OP_DW:                          # zero-margined tap rows for the MFMA depthwise stage
                     wi = op['wi']
                     k = wi.shape[2]

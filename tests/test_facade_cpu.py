@@ -323,3 +323,26 @@ def test_synthesize_zero_shot_calibration_data(tmp_path):
     assert os.path.basename(path) == 'syn_nb2_iter3_lr0.010.pkl'
     data = load_synthetic(path)
     assert len(data) == 2 and data[0].shape == (2, 16, 32)
+
+
+def test_w6_blob_is_sub_byte_packed(golden_dir):
+    """BASELINE config 3: 6-bit weights are stored 4 codes per 3 bytes (pack6, element order unchanged) and the depthwise
+    tap rows are derived on load, so the w6a6 blob of QuartzNet15x5 is <= 0.78x the w8a8 one; unpack6 (the host
+    restatement of the device expansion) returns the exact integers."""
+    from qasr.pack import F_W6PACK, Packer, pack6, unpack6
+    rng = np.random.default_rng(1)
+    a = rng.integers(-32, 32, 4096).astype(np.int8)
+    assert pack6(a).size == a.size * 3 // 4 and np.array_equal(unpack6(pack6(a)), a)
+    with pytest.raises(AssertionError):
+        pack6(np.array([40, 0, 0, 0], np.int8))
+    sizes = {}
+    for name in ('net_quartznet_w8a8', 'net_quartznet_w6a6'):
+        d = np.load(os.path.join(golden_dir, name + '.npz'))
+        meta = json.loads(str(d['meta']))
+        cfg = topology.quartznet15x5()
+        p = Packer(cfg, synth.make_state_dict(cfg, meta['seed']), d['act_min'], d['act_max'], meta['wbit'], meta['abit'])
+        blob, _ = p.pack()
+        sizes[name] = len(blob)
+        packed = [bool(o['flags'] & F_W6PACK) for o in p.final_ops if o['kind'] in (1, 2, 3)]
+        assert all(packed) if meta['wbit'] <= 6 else not any(packed)
+    assert sizes['net_quartznet_w6a6'] <= 0.78 * sizes['net_quartznet_w8a8'], sizes
