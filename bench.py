@@ -40,7 +40,7 @@ CONFIGS = {
     # name: (model, weight bits, act bits, batch per GPU, default steps in flight, BASELINE.json configuration)
     'quartznet': ('QuartzNet15x5Base-En', 8, 8, 32, 4, 2),
     'w6a6': ('QuartzNet15x5Base-En', 6, 6, 32, 4, 3),
-    'jasper': ('Jasper10x5Dr-En', 8, 8, 64, 2, 4),
+    'jasper': ('Jasper10x5Dr-En', 8, 8, 64, 4, 4),
 }
 
 _T0 = time.time()

@@ -94,6 +94,7 @@ struct qasr_engine {
   bool legacy_pw = false;              // QASR_LEGACY_PW=1: stand-alone 1x1 convs through the v1 kernel k_pw
   std::vector<int> fused_dw;           // per op: index of the DW op fused into this PW op, or -1
   std::vector<char> skip;              // per op: launched as part of the following op
+  bool dense_tile128 = true;           // QASR_DENSE_TILE128=0 keeps Jasper's dense convs on 64-frame tiles (A/B runs)
   bool wide_tiles = false;             // k_sep with 64-frame tiles (throughput mode: bit 3 of `debug`, or QASR_WIDE_TILES=1)
   bool use_utt = false;                // whole-utterance kernels k_utt (bit 2 of `debug`, or QASR_UTT=1)
   int sep_gen = 2;                     // 2: k_sep2 where it has the shape; 1 (QASR_SEP_GEN=1): k_sep everywhere (A/B runs)
@@ -350,6 +351,7 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
   e->debug = (debug & 1) != 0;
   e->fuse = getenv("QASR_NO_FUSE") == nullptr;
   e->legacy_pw = getenv("QASR_LEGACY_PW") != nullptr;
+  if (const char* g = getenv("QASR_DENSE_TILE128")) e->dense_tile128 = atoi(g) != 0;
   if (const char* g = getenv("QASR_SEP_GEN")) e->sep_gen = atoi(g) == 1 ? 1 : 2;
   // whole-utterance kernels (k_utt) are opt-in: bit 2 of `debug` or QASR_UTT=1 (throughput experiments)
   e->use_utt = (debug & 4) != 0 || getenv("QASR_UTT") != nullptr;
@@ -494,6 +496,12 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
       size_t xr = 0;
       for (int k = 0; k < p.n_panes; ++k) xr = std::max(xr, (size_t)64 * (p.panes[k].cin_pad + 16));
       if ((size_t)(64 + 2 * halo) * (p.cin_pad + 16) + xr + 37 * 1024 > 160 * 1024) p.tile = 32;
+      // plain dense convs in throughput mode: 128-frame tiles (every weight fragment feeds four frame tiles; a launch
+      // then has B * Tp / 128 work-groups and two launches of different steps share the chip) where the window fits
+      const TensorRT& o0 = e->tens[op.outs[0].tensor];
+      if (e->wide_tiles && e->dense_tile128 && p.n_panes == 0 && rup(o0.T, 64) % 128 == 0 &&
+          (size_t)(128 + 2 * halo) * (p.cin_pad + 16) + 37 * 1024 <= 160 * 1024)
+        p.tile = 128;
     }
   }
 }

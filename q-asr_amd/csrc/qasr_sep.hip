@@ -19,6 +19,8 @@ extern template int launch_sep2_inst<64, true>(hipStream_t, const SepP&);
 // k_sep2 takes the stride-1 separable layers it is built for (sep2_shape_ok) unless the engine was told to stay on k_sep
 bool sep2_takes(const SepP& p) { return p.gen == 2 && sep2_shape_ok(p); }
 
+int launch_sep_dense128(hipStream_t s, const SepP& p);   // qasr_sep_t128.hip
+
 bool sep_supported(int K, int dilation) {
   if (dilation == 2) return K == 87 || K == 15;
   return dilation == 1 && (K == 0 || K == 11 || K == 13 || K == 33 || K == 39 || K == 51 || K == 63 || K == 75);
@@ -40,6 +42,7 @@ void sep_kernel_label(const SepP& p, char* buf, size_t cap) {
 // tiles per wave (hundreds of spilled VGPRs): 1x1 ops of that class run with 32-frame tiles (QuartzNet decoder 32 -> 17 us).
 // Dense k > 1 convs keep the wide tile: halving their weight traffic outweighs the spills (Jasper 9.7 vs 9.9 ms).
 int sep_tile_for(const SepP& p) {
+  if (p.tile == 128 && p.dense_k > 1 && sep_epilogue_class(p) == EP_PLAIN) return 128;   // Jasper's plain dense convs
   return (p.tile == 64 && (p.dense_k > 1 || sep_epilogue_class(p) != EP_GENERIC)) ? 64 : 32;
 }
 
@@ -50,6 +53,7 @@ int launch_sep(hipStream_t s, const SepP& p) {
     return dbg ? launch_sep2_inst<32, true>(s, p) : launch_sep2_inst<32, false>(s, p);
   }
   if (!sep_supported(p.K, p.K > 0 ? p.dilation : 1)) return QASR_ERR_UNSUPPORTED;
+  if (sep_tile_for(p) == 128) return launch_sep_dense128(s, p);
   if (sep_tile_for(p) == 64) return dbg ? launch_sep_inst<64, true>(s, p) : launch_sep_inst<64, false>(s, p);
   return dbg ? launch_sep_inst<32, true>(s, p) : launch_sep_inst<32, false>(s, p);
 }

@@ -145,21 +145,22 @@ __device__ __forceinline__ void sep_mfma_d(v16i (&acc)[MT], const v4i (&wf)[SEP_
                                            int kc) {
   const int lane = threadIdx.x & 63, h = lane >> 5, r31 = lane & 31;
   const unsigned char* arow = Xrow + r31 * XP + kc + 16 * h;
-  v4i a[MT][4];
+  constexpr int AB = MT > 2 ? 2 : 4;                         // K steps whose A fragments are read ahead (register budget)
+  v4i a[MT][AB];
 #pragma unroll
-  for (int g = 0; g < SEP_DK / 4; ++g)
-    if (kc + 128 * g < cin_pad) {
+  for (int g = 0; g < SEP_DK / AB; ++g)
+    if (kc + 32 * AB * g < cin_pad) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[mt][i] = *(const v4i*)(arow + 32 * mt * XP + 32 * (4 * g + i));
+        for (int i = 0; i < AB; ++i) a[mt][i] = *(const v4i*)(arow + 32 * mt * XP + 32 * (AB * g + i));
       // all reads of the group are in flight before the first MFMA: left alone, the compiler sinks every ds_read next
       // to its MFMA and waits for it, which makes the tap loop LDS-latency bound (Jasper: 10.4 -> 9.9 ms)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)                         // every weight fragment feeds MT frame tiles
+      for (int i = 0; i < AB; ++i)                            // every weight fragment feeds MT frame tiles
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mt][i], wf[4 * g + i], acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mt][i], wf[AB * g + i], acc[mt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
 }
