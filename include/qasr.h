@@ -222,7 +222,8 @@ int qasr_requant(void* stream, const int32_t* acc, const double* m, const float*
  * is a device pointer in the blob's layouts (see qasr_op_desc): the parity tests drive the production kernels through
  * this entry with operands of their own making (accumulators beyond 2^22, rounding ties, ragged lengths).
  * K == 0: no depthwise stage (`x` feeds the 1x1 conv).  gen: 2 = k_sep2 where it has the shape, 1 = k_sep.
- * tile: 32 or 64 frames per work-group.  `label` (optional) receives the kernel instantiation that ran. */
+ * tile: 32, 64 or 128 (k_sep2's plain layers; others fall back to 64) frames per work-group.  `label` (optional)
+ * receives the kernel instantiation that ran. */
 typedef struct qasr_sep_layer_args {
   int32_t B, T, Tp, cin, cout, K, dilation, tile, gen;
   uint32_t flags;              /* QASR_F_RELU | MASK_OUT | EXACT_Z | RESADD */

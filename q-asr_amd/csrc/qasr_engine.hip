@@ -94,6 +94,7 @@ struct qasr_engine {
   bool legacy_pw = false;              // QASR_LEGACY_PW=1: stand-alone 1x1 convs through the v1 kernel k_pw
   std::vector<int> fused_dw;           // per op: index of the DW op fused into this PW op, or -1
   std::vector<char> skip;              // per op: launched as part of the following op
+  bool tile128 = true;                 // QASR_TILE128=0: k_sep2's plain layers stay on 64-frame tiles in throughput mode (A/B runs)
   bool dense_tile128 = true;           // QASR_DENSE_TILE128=0 keeps Jasper's dense convs on 64-frame tiles (A/B runs)
   bool wide_tiles = false;             // k_sep with 64-frame tiles (throughput mode: bit 3 of `debug`, or QASR_WIDE_TILES=1)
   bool use_utt = false;                // whole-utterance kernels k_utt (bit 2 of `debug`, or QASR_UTT=1)
@@ -351,6 +352,7 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
   e->debug = (debug & 1) != 0;
   e->fuse = getenv("QASR_NO_FUSE") == nullptr;
   e->legacy_pw = getenv("QASR_LEGACY_PW") != nullptr;
+  if (const char* g = getenv("QASR_TILE128")) e->tile128 = atoi(g) != 0;
   if (const char* g = getenv("QASR_DENSE_TILE128")) e->dense_tile128 = atoi(g) != 0;
   if (const char* g = getenv("QASR_SEP_GEN")) e->sep_gen = atoi(g) == 1 ? 1 : 2;
   // whole-utterance kernels (k_utt) are opt-in: bit 2 of `debug` or QASR_UTT=1 (throughput experiments)
@@ -459,7 +461,7 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
   p.cin = (int)op.cin;
   p.cin_pad = rup(p.cin, 128);
   p.n_panes = (int)op.n_panes;
-  p.tile = e->wide_tiles ? 64 : 32;
+  p.tile = e->wide_tiles ? (e->tile128 ? 128 : 64) : 32;   // 128: k_sep2's plain layers only (sep2_tile), everything else 64
   p.gen = e->sep_gen;
   fill_panes(e, oi, op, p.panes);
   fill_epi(e, oi, op, p.e);
@@ -495,6 +497,7 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
       const int halo = ((p.dense_k - 1) * p.dilation / 2 + 3) & ~3;
       size_t xr = 0;
       for (int k = 0; k < p.n_panes; ++k) xr = std::max(xr, (size_t)64 * (p.panes[k].cin_pad + 16));
+      if (p.tile > 64) p.tile = 64;
       if ((size_t)(64 + 2 * halo) * (p.cin_pad + 16) + xr + 37 * 1024 > 160 * 1024) p.tile = 32;
       // plain dense convs in throughput mode: 128-frame tiles (every weight fragment feeds four frame tiles; a launch
       // then has B * Tp / 128 work-groups and two launches of different steps share the chip) where the window fits
@@ -890,7 +893,7 @@ int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t
 
 int qasr_sep_layer(void* stream, const qasr_sep_layer_args* a, char* label, size_t label_cap) {
   if (!a || !a->x || !a->w || !a->bias || !a->lens || a->B < 1 || a->cin < 1 || a->cout < 1 || a->Tp % 64 || a->T > a->Tp ||
-      a->n_outs < 0 || a->n_outs > QASR_MAX_OUTS || (a->tile != 32 && a->tile != 64))
+      a->n_outs < 0 || a->n_outs > QASR_MAX_OUTS || (a->tile != 32 && a->tile != 64 && a->tile != 128))
     return fail(QASR_ERR_ARG, "sep_layer: bad arguments");
   SepP p{};
   p.x = a->x;

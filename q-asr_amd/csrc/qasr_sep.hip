@@ -15,9 +15,17 @@ extern template int launch_sep2_inst<32, false>(hipStream_t, const SepP&);
 extern template int launch_sep2_inst<32, true>(hipStream_t, const SepP&);
 extern template int launch_sep2_inst<64, false>(hipStream_t, const SepP&);
 extern template int launch_sep2_inst<64, true>(hipStream_t, const SepP&);
+extern template int launch_sep2_inst<128, false>(hipStream_t, const SepP&);
+extern template int launch_sep2_inst<128, true>(hipStream_t, const SepP&);
 
 // k_sep2 takes the stride-1 separable layers it is built for (sep2_shape_ok) unless the engine was told to stay on k_sep
 bool sep2_takes(const SepP& p) { return p.gen == 2 && sep2_shape_ok(p); }
+// frames per work-group of a k_sep2 launch: 128 for plain layers when the engine asks for it (throughput mode: every
+// weight fragment then feeds four frame tiles, B * Tp / 128 work-groups per launch), else the engine's 32 / 64
+static int sep2_tile(const SepP& p) {
+  if (p.tile == 128) return (!(p.e.flags & QASR_F_RESADD) && p.K > 0 && p.e.Tp % 128 == 0) ? 128 : 64;
+  return p.tile == 64 ? 64 : 32;
+}
 
 int launch_sep_dense128(hipStream_t s, const SepP& p);   // qasr_sep_t128.hip
 
@@ -31,7 +39,7 @@ void sep_kernel_label(const SepP& p, char* buf, size_t cap) {
   const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
   if (sep2_takes(p)) {
     snprintf(buf, cap, "k_sep2<%d, %d, %d, %d, %s, %d>", p.K, p.cin_pad >> 7, (p.e.flags & QASR_F_RESADD) ? p.panes[0].cin_pad >> 7 : 0,
-             (p.e.cout + 255) / 256, dbg ? "true" : "false", p.tile == 64 ? 64 : 32);
+             (p.e.cout + 255) / 256, dbg ? "true" : "false", sep2_tile(p));
     return;
   }
   snprintf(buf, cap, "k_sep<%d, %d, %d, %s, %d>", p.K, p.K > 0 ? p.dilation : 1, sep_epilogue_class(p), dbg ? "true" : "false",
@@ -43,13 +51,15 @@ void sep_kernel_label(const SepP& p, char* buf, size_t cap) {
 // Dense k > 1 convs keep the wide tile: halving their weight traffic outweighs the spills (Jasper 9.7 vs 9.9 ms).
 int sep_tile_for(const SepP& p) {
   if (p.tile == 128 && p.dense_k > 1 && sep_epilogue_class(p) == EP_PLAIN) return 128;   // Jasper's plain dense convs
-  return (p.tile == 64 && (p.dense_k > 1 || sep_epilogue_class(p) != EP_GENERIC)) ? 64 : 32;
+  return (p.tile >= 64 && (p.dense_k > 1 || sep_epilogue_class(p) != EP_GENERIC)) ? 64 : 32;
 }
 
 int launch_sep(hipStream_t s, const SepP& p) {
   const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
   if (sep2_takes(p)) {
-    if (p.tile == 64) return dbg ? launch_sep2_inst<64, true>(s, p) : launch_sep2_inst<64, false>(s, p);
+    const int tt = sep2_tile(p);
+    if (tt == 128) return dbg ? launch_sep2_inst<128, true>(s, p) : launch_sep2_inst<128, false>(s, p);
+    if (tt == 64) return dbg ? launch_sep2_inst<64, true>(s, p) : launch_sep2_inst<64, false>(s, p);
     return dbg ? launch_sep2_inst<32, true>(s, p) : launch_sep2_inst<32, false>(s, p);
   }
   if (!sep_supported(p.K, p.K > 0 ? p.dilation : 1)) return QASR_ERR_UNSUPPORTED;

@@ -59,20 +59,22 @@ struct Sep2Geo {
   static constexpr int MS = -(D & 3);                    // first tap offset: keeps the window dwords 4-byte aligned
   static constexpr int NS = (K + 3 - MS + 3) / 4;        // MFMA steps per chain
   static constexpr int A0 = D + MS;                      // byte offset of window dword 0 (multiple of 4)
-  static constexpr int OFF = (A0 & (S - 1)) / 4;         // dwords skipped at the head of the S-aligned lane stream
+  static constexpr int RG = S < 16 ? S : 16;             // LDS read granule of the lane stream (ds_read_b64 / b128)
+  static constexpr int OFF = (A0 & (RG - 1)) / 4;        // dwords skipped at the head of the RG-aligned lane stream
   static constexpr int NE = OFF + NU + NS - 1;           // dwords of the lane stream
-  static constexpr int NRD = (4 * NE + S - 1) / S;       // S-byte LDS reads per lane and group
+  static constexpr int NRD = (4 * NE + RG - 1) / RG;     // RG-byte LDS reads per lane and group
   static constexpr int WLEN = TT + 2 * HALO;             // staged bytes per window row
   // LDS row pitch: the lanes of one LDS access group read S-byte runs of 4 (b128) / 8 (b64) different rows; an odd
   // multiple of 4 S bytes puts those rows on disjoint banks (a power-of-two pitch made every read 4-way conflicted)
-  static constexpr int WP = ((WLEN + 4 * S - 1) / (4 * S) | 1) * (4 * S);
+  // (128-frame tiles keep the dense pitch: the conflict-free one would not fit the LDS next to the 64 KiB A image)
+  static constexpr int WP = TT > 64 ? WLEN : ((WLEN + 4 * S - 1) / (4 * S) | 1) * (4 * S);
   static constexpr int NPG = WLEN / 16;                  // 16-B granules per row
   static constexpr int NPT = (SEP2_CH * NPG + SEP2_NT - 1) / SEP2_NT;   // window granules per thread and chunk
   static constexpr int KP4 = (K + 3) / 4;
   static constexpr int KS = 4 * KP4 + 32;                // row pitch of the zero-margined tap array (pack.py)
   static constexpr int TAPB = SEP2_CH * KS;              // tap bytes of a chunk (256 KS is a multiple of 16)
   static constexpr int NTT = (TAPB / 16 + SEP2_NT - 1) / SEP2_NT;       // tap granules per thread and chunk
-  static_assert(3 * S + (A0 & ~(S - 1)) + NRD * S <= WLEN && WLEN <= WP, "lane stream leaves the window row");
+  static_assert(3 * S + (A0 & ~(RG - 1)) + NRD * RG <= WLEN && WLEN <= WP, "lane stream leaves the window row");
   static_assert(8 + MS - 3 >= 0 && 8 + MS + 4 * (NS + 1) <= KS, "tap stream leaves the tap row");
   static_assert(TAPB % 16 == 0, "tap chunk is not 16-byte granular");
 };
@@ -116,26 +118,28 @@ __device__ __forceinline__ void sep2_load_wg(v4i* wb, const v4i* __restrict__ wp
 template <int MT, int N, int N0>
 __device__ __forceinline__ void sep2_gemm(v16i (&acc)[MT], v4i (&wf)[16], const lds_u8* img_lane, int mt_stride,
                                           const v4i* __restrict__ r0, const v4i* __restrict__ r1) {
-  v4i a[2][MT][2];
+  constexpr int AB = MT > 2 ? 1 : 2;                         // K steps per A-fragment batch (register budget at MT = 4)
+  constexpr int NQ = 4 * N / AB;
+  v4i a[2][MT][AB];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[0][mt][i] = sep2_a_frag(img_lane + mt * mt_stride, i);
+    for (int i = 0; i < AB; ++i) a[0][mt][i] = sep2_a_frag(img_lane + mt * mt_stride, i);
 #pragma unroll
-  for (int q = 0; q < 2 * N; ++q) {                          // pair of K steps; group g = q >> 1
-    if (q + 1 < 2 * N) {
+  for (int q = 0; q < NQ; ++q) {                             // batch of AB K steps; group g = q * AB / 4
+    if (q + 1 < NQ) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[(q + 1) & 1][mt][i] = sep2_a_frag(img_lane + mt * mt_stride, 2 * (q + 1) + i);
+        for (int i = 0; i < AB; ++i) a[(q + 1) & 1][mt][i] = sep2_a_frag(img_lane + mt * mt_stride, AB * (q + 1) + i);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < AB; ++i)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q & 1][mt][i], wf[2 * q + i], acc[mt], 0, 0, 0);
-    if (q & 1) {
-      const int g = q >> 1;
+        acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q & 1][mt][i], wf[AB * q + i], acc[mt], 0, 0, 0);
+    if ((AB * (q + 1)) % 4 == 0) {
+      const int g = (AB * (q + 1)) / 4 - 1;
       if (g < N0) {
         if (r0) sep2_load_wg(&wf[4 * g], r0 + 256 * g);
       } else {
@@ -310,17 +314,17 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   const int e0 = e0base - jl, tq = e0 >> 2, tsh = e0 & 3;
   struct DwIn {                                              // LDS operands of one group of 16 channels
     unsigned raw[NS + 1];                                    // the lane's tap dwords (whole words, funnel-shifted later)
-    unsigned xs[G::NRD * (S / 4)];                           // the lane's window run: every dword feeds the NU chains
+    unsigned xs[G::NRD * (G::RG / 4)];                       // the lane's window run: every dword feeds the NU chains
   };
   auto dw_read = [&](DwIn& in, int g) {
     const int row = 32 * wave + 16 * g + cb;
     const lds_u32* tr = (const lds_u32*)(Tl + row * G::KS + 4 * tq);
 #pragma unroll
     for (int i = 0; i <= NS; ++i) in.raw[i] = tr[i];
-    const lds_u8* wr = Ws + row * G::WP + S * jl + (G::A0 & ~(S - 1));
+    const lds_u8* wr = Ws + row * G::WP + S * jl + (G::A0 & ~(G::RG - 1));
 #pragma unroll
     for (int i = 0; i < G::NRD; ++i) {
-      if constexpr (S == 16) {
+      if constexpr (G::RG == 16) {
         const v4i v = *(const lds_v4i*)(wr + 16 * i);
         in.xs[4 * i] = v[0]; in.xs[4 * i + 1] = v[1]; in.xs[4 * i + 2] = v[2]; in.xs[4 * i + 3] = v[3];
       } else {
@@ -394,11 +398,19 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
       for (int gi = 0; gi < 2 * NCHUNK; ++gi) asm volatile("" : "+v"(dbias[gi]), "+v"(dM[gi]));
     }
     STAMP2();
-    DwIn inA, inB;
-    dw_read(inA, 0);
-    dw_read(inB, 1);
-    dw_math(inA, c0, 0, dbias[2 * CH], dM[2 * CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
-    dw_math(inB, c0, 1, dbias[2 * CH + 1], dM[2 * CH + 1], [&](int k) { pf(chc, Q * (3 + k), Q * (4 + k)); });
+    if constexpr (TT > 64) {                                 // register budget: one operand set at a time
+      DwIn in;
+      dw_read(in, 0);
+      dw_math(in, c0, 0, dbias[2 * CH], dM[2 * CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
+      dw_read(in, 1);
+      dw_math(in, c0, 1, dbias[2 * CH + 1], dM[2 * CH + 1], [&](int k) { pf(chc, Q * (3 + k), Q * (4 + k)); });
+    } else {                                                 // both groups' LDS operands in flight before the first MFMA
+      DwIn inA, inB;
+      dw_read(inA, 0);
+      dw_read(inB, 1);
+      dw_math(inA, c0, 0, dbias[2 * CH], dM[2 * CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
+      dw_math(inB, c0, 1, dbias[2 * CH + 1], dM[2 * CH + 1], [&](int k) { pf(chc, Q * (3 + k), Q * (4 + k)); });
+    }
     STAMP2();
   };
   if constexpr (K > 0) {
@@ -629,8 +641,10 @@ static int launch_sep2_v(hipStream_t s, const SepP& p) {
 template <int TT, bool DBG>
 int launch_sep2_inst(hipStream_t s, const SepP& p) {
   const int ng = p.cin_pad >> 7, ngp = (p.e.flags & QASR_F_RESADD) ? (p.panes[0].cin_pad >> 7) : 0, np = (p.e.cout + 255) / 256;
-#define SEP2_LAUNCH(K_, NG_, NGP_, NP_) \
-  if (p.K == K_ && ng == NG_ && ngp == NGP_ && np == NP_) return launch_sep2_v<K_, NG_, NGP_, NP_, DBG, TT>(s, p);
+#define SEP2_LAUNCH(K_, NG_, NGP_, NP_)                                                  \
+  if constexpr (TT <= 64 || NGP_ == 0) {                                                 \
+    if (p.K == K_ && ng == NG_ && ngp == NGP_ && np == NP_) return launch_sep2_v<K_, NG_, NGP_, NP_, DBG, TT>(s, p); \
+  }
   SEP2_INSTANCES(SEP2_LAUNCH)
 #undef SEP2_LAUNCH
   return QASR_ERR_UNSUPPORTED;

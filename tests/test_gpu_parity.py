@@ -465,7 +465,8 @@ SEP_SHAPES = [(33, 256, 256, 0), (39, 256, 256, 256), (51, 256, 512, 0), (51, 51
               (63, 512, 512, 0), (63, 512, 512, 512), (75, 512, 512, 0), (75, 512, 512, 512)]
 
 
-@pytest.mark.parametrize('gen,tile', [(2, 32), (2, 64), (1, 32), (1, 64)], ids=['k_sep2_32', 'k_sep2_64', 'k_sep_32', 'k_sep_64'])
+@pytest.mark.parametrize('gen,tile', [(2, 32), (2, 64), (2, 128), (1, 32), (1, 64)],
+                         ids=['k_sep2_32', 'k_sep2_64', 'k_sep2_128', 'k_sep_32', 'k_sep_64'])
 @pytest.mark.parametrize('K,cin,cout,rcin', SEP_SHAPES)
 def test_sep_layer_against_oracle(eng, gen, tile, K, cin, cout, rcin):
     """The fused separable-layer kernels at operator level (qasr_sep_layer): every production tap count / channel shape of
