@@ -58,9 +58,10 @@ def parse_args(argv=None):
     ap.add_argument('--config', choices=sorted(CONFIGS), default='quartznet',
                     help='quartznet = BASELINE.json config 2 (headline); w6a6 = config 3; jasper = config 4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--tile', type=int, default=0, choices=[0, 32, 64],
-                    help='frames per work-group of the separable-layer kernels: 32 = lowest single-step latency, 64 = less '
-                         'weight/halo traffic per frame but half the work-groups; 0 = 64 when more than one step is in flight')
+    ap.add_argument('--tile', type=int, default=0, choices=[0, 32, 64, 128],
+                    help='frames per work-group of the separable-layer kernels: 32 = lowest single-step latency; 64 / 128 = '
+                         'less weight / halo / tap-row traffic per frame but 1/2, 1/4 of the work-groups (128: the plain '
+                         'k_sep2 layers only, the rest stays on 64); 0 = 128 when more than one step is in flight, else 32')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel instead of replaying the captured hipGraph')
     ap.add_argument('--whole-utterance', action='store_true', help='use the k_utt kernels (one work-group per utterance)')
     ap.add_argument('--streams', type=int, default=int(os.environ.get('QASR_BENCH_STREAMS', 0)),
@@ -206,7 +207,9 @@ def dominant_kernel_roofline(eng, cfg, meta, ms, B, T):
     # the fused depthwise taps run on the matrix cores too (v_mfma_i32_4x4x4), so they count towards the MFMA bound
     t_mfma, t_hbm = (mfma + vdot) / n / PEAK_INT8_OPS, byts / n / PEAK_HBM
     serial = float(sum(ms))
-    out = {'kernel': 'qasr::' + lab, 'launches_per_step': n, 'avg_launch_us': 1e6 * t,
+    tt = int(lab.rstrip('>').split(',')[-1]) if lab.startswith('k_sep') else 0   # frames per work-group (last template arg)
+    out = {'kernel': 'qasr::' + lab, 'launches_per_step': n, 'avg_launch_us': 1e6 * t, '_ops': ops_l,
+           '_wgs': B * (-(-T // tt)) if tt else None,
            'share_of_step_device_time': tot[lab] / serial,
            'algorithmic_bytes_per_launch': byts / n, 'mfma_ops_per_launch': mfma / n,
            'depthwise_ops_per_launch': vdot / n, 'traffic': traffic.get(lab)}
@@ -222,6 +225,34 @@ def dominant_kernel_roofline(eng, cfg, meta, ms, B, T):
                           f'dispatch average, bytes, read from the committed summary profiles/{traffic_src}_pmc_*.txt '
                           '(not collected in this run); null = that summary has no row for this kernel'}
     return out
+
+
+def pair_timing(lane, roof, ops, reps=20):
+    """The dominant kernel with a second, independent launch of itself in flight (two engines, two HIP streams): a
+    128-frame-tile launch of a 32-utterance batch has 128 work-groups for 256 CUs, so the single-launch figure above
+    leaves half the chip idle by construction; this is the per-launch cost the timed region (4 steps in flight) sees."""
+    import torch
+    e0, e1 = lane['engs'][:2]
+    s0, s1 = lane['streams'][:2]
+    for e_, s_ in ((e0, s0), (e1, s1)):
+        for o in ops:
+            e_.run_op(o, stream=s_)
+    torch.cuda.synchronize()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(2)]
+    ev[0][0].record(s0), ev[1][0].record(s1)
+    for _ in range(reps):
+        for o in ops:
+            e0.run_op(o, stream=s0)
+            e1.run_op(o, stream=s1)
+    ev[0][1].record(s0), ev[1][1].record(s1)
+    torch.cuda.synchronize()
+    ms = max(ev[0][0].elapsed_time(ev[0][1]), ev[1][0].elapsed_time(ev[1][1]))
+    t = ms * 1e-3 / (2 * reps * len(ops))                        # s per launch, two streams' launches counted
+    return {'effective_launch_us': 1e6 * t, 'achieved_gb_s': roof['algorithmic_bytes_per_launch'] / t / 1e9,
+            'hbm_frac': roof['algorithmic_bytes_per_launch'] / t / PEAK_HBM,
+            'mfma_frac': (roof['mfma_ops_per_launch'] + roof['depthwise_ops_per_launch']) / t / PEAK_INT8_OPS,
+            'timing': f'{reps} x the kernel\'s launches of one step on each of two HIP streams (two engines), HIP events '
+                      'recorded on those streams; elapsed / launches'}
 
 
 def build_model(device, model_name, wbit, abit):
@@ -337,11 +368,13 @@ def run(args):
 
     T_pad = lib.qasr_frontend_frames(SAMPLES, 16)
     lib_ws = lib.qasr_frontend_workspace_bytes(BATCH, SAMPLES, 64)
+    fe_plan = engine.frontend_plan(fb)     # filterbank-only tables, built once like a model does (ctc_models._frontend_hip)
 
     def make_lane(S, tile):
         """S steps in flight: per step in flight an engine (own arena), a HIP stream, its own audio batch and its own
         feature / length / token buffers (stable pointers: the forward replays as one hipGraph launch)."""
-        engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance, wide_tiles=(tile == 64),
+        os.environ['QASR_TILE128'] = '1' if tile == 128 else '0'   # read by qasr_engine_create
+        engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance, wide_tiles=(tile >= 64),
                               graph=not args.no_graph) for _ in range(S)]
         streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
         T_out = engs[0].out_frames(T_pad)
@@ -361,7 +394,7 @@ def run(args):
         with torch.cuda.stream(lane['streams'][k]):
             if b['gathered'] is not None:                    # the gather of this buffer set's previous step read `tokens`
                 lane['streams'][k].wait_event(b['gathered'])
-            feats, flen = engine.frontend_mel(lane['audio'][k], alen, fb, window, 0.97, 16, out=b['fe'])
+            feats, flen = engine.frontend_mel(lane['audio'][k], alen, fb, window, 0.97, 16, out=b['fe'], plan=fe_plan)
             _, tokens, _ = lane['engs'][k].forward(feats, flen, want_logp=False, out=b['out'])
             done = torch.cuda.Event()
             done.record(lane['streams'][k])
@@ -413,7 +446,7 @@ def run(args):
     # throughput mode: consecutive steps are independent batches, so S of them are kept in flight, each on its own
     # HIP stream with its own engine arena (kernels of different steps overlap each other's launch gaps and tails)
     S = max(1, args.streams or S_default)
-    tile = args.tile or (64 if S > 1 else 32)
+    tile = args.tile or (128 if S > 1 else 32)
     lane = make_lane(S, tile)
     eng = lane['engs'][0]
     T_out = lane['T_out']
@@ -440,7 +473,7 @@ def run(args):
                    'global_batch': BATCH * world, 'seq_len': FRAMES, 'weights': 'random-init (qasr.synth, seed 0)',
                    'steps_in_flight': S, 'inputs': 'one audio batch per step in flight (different seeds)',
                    'hip_graph': not args.no_graph,
-                   'kernels': 'k_utt' if args.whole_utterance else f'k_sep2 / k_sep, {tile}-frame tiles',
+                   'kernels': 'k_utt' if args.whole_utterance else f'k_sep2 / k_sep, {tile}-frame tiles' + (' (64 where a layer has residual panes)' if tile == 128 else ''),
                    'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + token gather' if world > 1 else ''),
                    'wer': 'not measurable here: no LibriSpeech / checkpoint in the image'},
     }
@@ -452,6 +485,9 @@ def run(args):
         torch.cuda.synchronize()
         ms = eng.time_ops(reps=20).astype(np.float64)
         result['roofline'] = dominant_kernel_roofline(eng, cfg, meta, ms, BATCH, FRAMES // 2)
+        dom_ops = result['roofline'].pop('_ops')
+        if S > 1:
+            result['roofline']['other']['two_in_flight'] = pair_timing(lane, result['roofline'], dom_ops)
         mfma_ops, dw_ops, step_bytes = algorithmic_work(cfg, BATCH, FRAMES // 2)
         # whole-step view (all launches, steps in flight as timed): SURVEY §8d bytes = every conv reads its int8 input
         # once, writes its output once, weights once
@@ -460,7 +496,7 @@ def run(args):
                                            step_mfma_frac=mfma_ops / (dt / args.steps) / PEAK_INT8_OPS,
                                            step_algorithmic_gb_s=step_bytes / (dt / args.steps) / 1e9,
                                            step_hbm_frac=step_bytes / (dt / args.steps) / PEAK_HBM,
-                                           work_groups_per_launch=BATCH * 256 // tile)
+                                           work_groups_per_launch=result['roofline'].pop('_wgs', None))
     for e_ in lane['engs']:
         e_.close()
 

@@ -194,10 +194,18 @@ int qasr_quantile2(void* stream, const float* x, size_t n, float q_lo, float q_h
  * power, mel filterbank, log, per-feature normalisation, mask, pad to a multiple of `pad_to`.
  * audio f32 [B][S]; audio_lens i32 [B] (samples); fb f32 [n_mels][257]; window f32 [320];
  * feats f32 [B][n_mels][T_pad]; feat_lens i32 [B].  T_pad = qasr_frontend_frames(S, pad_to).
- * workspace: device scratch of qasr_frontend_workspace_bytes(B, S, n_mels) bytes (non-zero run of every mel filter). */
+ * workspace: device memory of qasr_frontend_workspace_bytes(B, S, n_mels) bytes, 16-byte aligned: tables that depend
+ * on the filterbank only (non-zero run of every mel filter, the runs' weights packed back to back, FFT twiddles).
+ * qasr_frontend_mel fills them and runs (self-contained, 5 launches).  A caller whose filterbank is fixed — every
+ * model is — calls qasr_frontend_plan once and qasr_frontend_mel_planned per batch (2 launches: k_mel, k_norm); the
+ * workspace is read-only from then on and may be shared by any number of streams. */
 int qasr_frontend_mel(void* stream, const float* audio, const int32_t* audio_lens, int B, int S,
                       const float* fb, const float* window, int n_mels, float preemph, int pad_to,
                       float* feats, int32_t* feat_lens, void* workspace, size_t workspace_bytes);
+int qasr_frontend_plan(void* stream, const float* fb, int n_mels, void* workspace, size_t workspace_bytes);
+int qasr_frontend_mel_planned(void* stream, const float* audio, const int32_t* audio_lens, int B, int S,
+                              const float* fb, const float* window, int n_mels, float preemph, int pad_to,
+                              float* feats, int32_t* feat_lens, const void* workspace, size_t workspace_bytes);
 int qasr_frontend_frames(int S, int pad_to);
 size_t qasr_frontend_workspace_bytes(int B, int S, int n_mels);
 

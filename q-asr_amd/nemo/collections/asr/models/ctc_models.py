@@ -226,8 +226,13 @@ class EncDecCTCModel(nn.Module):
             return self.preprocessor(input_signal=signal, length=length)
         if f.dither > 0:
             signal = signal + f.dither * torch.randn_like(signal)
-        return qengine.frontend_mel(signal.float().contiguous(), length, f.fb[0].contiguous(), f.window.contiguous(),
-                                    float(f.preemph), int(f.pad_to))
+        fb = f.fb[0].to(device=signal.device, dtype=torch.float32).contiguous()
+        key = (fb.data_ptr(), f.fb._version, str(signal.device))
+        if getattr(self, '_frontend_plan_key', None) != key:   # filterbank-only tables: built once per model / device
+            self._frontend_plan = qengine.frontend_plan(fb)
+            self._frontend_plan_key = key
+        return qengine.frontend_mel(signal.float().contiguous(), length, self._frontend_plan._qasr_fb, f.window.contiguous(),
+                                    float(f.preemph), int(f.pad_to), plan=self._frontend_plan)
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_signal=None, input_signal_length=None, processed_signal=None,

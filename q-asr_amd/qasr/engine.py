@@ -12,7 +12,8 @@ LIB_PATH = os.environ.get('QASR_LIB', os.path.join(HERE, 'libqasr_hip.so'))   # 
 SYMBOLS = ['qasr_engine_create', 'qasr_engine_destroy', 'qasr_engine_forward', 'qasr_engine_out_frames',
            'qasr_engine_num_ops', 'qasr_engine_read_acc', 'qasr_engine_read_tensor', 'qasr_engine_last_op_ms',
            'qasr_engine_time_ops', 'qasr_engine_run_op', 'qasr_engine_op_label',
-           'qasr_frontend_mel', 'qasr_frontend_frames', 'qasr_frontend_workspace_bytes', 'qasr_pw_conv_acc',
+           'qasr_frontend_mel', 'qasr_frontend_plan', 'qasr_frontend_mel_planned', 'qasr_frontend_frames',
+           'qasr_frontend_workspace_bytes', 'qasr_pw_conv_acc',
            'qasr_dw_conv_acc', 'qasr_requant', 'qasr_sep_layer', 'qasr_quantile2', 'qasr_quantile_workspace_bytes', 'qasr_debug_prof',
            'qasr_last_error', 'qasr_version']
 
@@ -62,6 +63,8 @@ def load_library():
     lib.qasr_engine_run_op.argtypes = [vp, vp, i32]
     lib.qasr_engine_op_label.argtypes = [vp, i32, C.c_char_p, sz]
     lib.qasr_frontend_mel.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, C.c_float, i32, vp, vp, vp, sz]
+    lib.qasr_frontend_mel_planned.argtypes = lib.qasr_frontend_mel.argtypes
+    lib.qasr_frontend_plan.argtypes = [vp, vp, i32, vp, sz]
     lib.qasr_frontend_frames.argtypes = [i32, i32]
     lib.qasr_frontend_workspace_bytes.argtypes = [i32, i32, i32]
     lib.qasr_frontend_workspace_bytes.restype = sz
@@ -366,17 +369,30 @@ def sep_layer(x, lens, wpw, bias, outs, wdw=None, m_dw=None, dw_range=(-128, 127
                 **{k: (hk[k][:, :, :T] if k in hk else None) for k in ('dw_acc', 'acc', 'racc')})
 
 
+def frontend_plan(fb: torch.Tensor):
+    """qasr_frontend_plan: the filterbank-only tables of the front-end (filter runs, packed weights, twiddles) as a
+    workspace tensor for frontend_mel(..., plan=...).  Read-only afterwards; one plan serves any number of streams."""
+    lib = load_library()
+    assert fb.is_cuda and fb.dtype == torch.float32 and fb.is_contiguous() and fb.dim() == 2 and fb.shape[1] == 257
+    ws = torch.empty(max(lib.qasr_frontend_workspace_bytes(0, 0, fb.shape[0]), 16), dtype=torch.uint8, device=fb.device)
+    _check(lib.qasr_frontend_plan(_stream_ptr(), _ptr(fb), fb.shape[0], _ptr(ws), ws.numel()), 'qasr_frontend_plan')
+    ws._qasr_fb = fb                                          # the table is only valid for this filterbank: keep it alive
+    return ws
+
+
 def frontend_mel(audio: torch.Tensor, lens: torch.Tensor, fb: torch.Tensor, window: torch.Tensor, preemph=0.97,
-                 pad_to=16, out=None):
+                 pad_to=16, out=None, plan=None):
     """qasr_frontend_mel: audio f32 [B,S] (cuda), lens [B] samples, fb [n_mels,257], window [320]
-    -> (features f32 [B,n_mels,T_pad], feature lengths i32 [B])."""
+    -> (features f32 [B,n_mels,T_pad], feature lengths i32 [B]).
+    out = caller-owned (features, lengths, workspace); plan = frontend_plan(fb) of the same filterbank: skips the
+    per-call table build (qasr_frontend_mel_planned)."""
     lib = load_library()
     assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 2
     B, S = audio.shape
     n_mels = fb.shape[0]
     dev = audio.device
     T_pad = lib.qasr_frontend_frames(S, pad_to)
-    if out is not None:                                      # caller-owned (features, lengths, workspace)
+    if out is not None:
         feats, flens, ws_out = out
     else:
         feats = torch.empty(B, n_mels, T_pad, device=dev, dtype=torch.float32)
@@ -386,6 +402,11 @@ def frontend_mel(audio: torch.Tensor, lens: torch.Tensor, fb: torch.Tensor, wind
     l32 = lens.to(device=dev, dtype=torch.int32).contiguous()
     fbd = fb.to(device=dev, dtype=torch.float32).contiguous()
     wd = window.to(device=dev, dtype=torch.float32).contiguous()
+    if plan is not None:
+        _check(lib.qasr_frontend_mel_planned(_stream_ptr(), _ptr(a), _ptr(l32), B, S, _ptr(fbd), _ptr(wd), n_mels,
+                                             C.c_float(preemph), pad_to, _ptr(feats), _ptr(flens), _ptr(plan), plan.numel()),
+               'qasr_frontend_mel_planned')
+        return feats, flens
     ws_bytes = lib.qasr_frontend_workspace_bytes(B, S, n_mels)
     ws = ws_out if ws_out is not None else torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
     _check(lib.qasr_frontend_mel(_stream_ptr(), _ptr(a), _ptr(l32), B, S, _ptr(fbd), _ptr(wd), n_mels,

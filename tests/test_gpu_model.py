@@ -44,6 +44,26 @@ def test_frontend_hip_matches_reference(golden_dir):
         assert np.all(y[b, :, n:] == 0)          # masked + pad_to frames are exactly zero
 
 
+def test_frontend_planned_equals_self_contained(golden_dir):
+    """qasr_frontend_plan + qasr_frontend_mel_planned (what a model with a fixed filterbank calls per batch) is the same
+    computation as the self-contained qasr_frontend_mel: bit-identical features; and a filterbank too large for the
+    LDS table (here: more filters than MEL_MAXM) takes the global-memory projection with the same result per filter."""
+    from qasr import engine
+    d = np.load(os.path.join(golden_dir, 'frontend.npz'))
+    audio, lens = torch.from_numpy(d['audio']).cuda(), torch.from_numpy(d['lens']).cuda()
+    fb, win = torch.from_numpy(d['fb']).cuda().contiguous(), torch.from_numpy(d['window']).cuda()
+    y0, s0 = engine.frontend_mel(audio, lens, fb, win, 0.97, 16)
+    plan = engine.frontend_plan(fb)
+    for _ in range(2):                                         # the plan is read-only: reusable
+        y1, s1 = engine.frontend_mel(audio, lens, fb, win, 0.97, 16, plan=plan)
+        assert torch.equal(y0, y1) and torch.equal(s0, s1)
+    big = torch.cat([fb, fb, fb.flip(0)[:8]]).contiguous()     # 136 filters > MEL_MAXM: read from global memory
+    yb, _ = engine.frontend_mel(audio, lens, big, win, 0.97, 16)
+    n = fb.shape[0]
+    assert torch.equal(yb[:, :n], y0) and torch.equal(yb[:, n:2 * n], y0)
+    assert torch.equal(yb[:, 2 * n:], y0.flip(1)[:, :8])
+
+
 def _prepared_model(name='MiniQuartzNet', seed=1, wbit=8, abit=8, percentile=None, feat=16, frames=96):
     m = EncDecCTCModel.from_synthetic(name, seed=seed).cuda()
     m.eval()
