@@ -215,14 +215,49 @@ size_t qasr_frontend_workspace_bytes(int B, int S, int n_mels);
  * W[32*tile + (lane & 31)][32*ks + 16*(lane >> 5) + j]; acc i32 [B][cout][Tp].  T valid columns. */
 int qasr_pw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, const int32_t* bias,
                      int B, int cin, int cin_pad, int cout, int T, int Tp, int32_t* acc);
-/* depthwise int_conv accumulator: w s8 [c][kpad]; acc i32 [B][c][Tp_out] */
-int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, int B, int c, int kernel,
-                     int kpad, int stride, int dilation, int padding, int T, int Tp, int T_out, int Tp_out,
+/* depthwise int_conv accumulator: w s8 [c][kpad]; acc i32 [B][c][Tp_out]; bias i32 [c] or NULL (x_unsigned: bytes
+ * are u8 and the kernel feeds x - 128, so bias carries 128 * sum(w[c]) to give the accumulator of the u8 codes) */
+int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, const int32_t* bias, int B, int c,
+                     int kernel, int kpad, int stride, int dilation, int padding, int T, int Tp, int T_out, int Tp_out,
                      int32_t* acc);
 /* fixedpoint_mul.forward for one operand (quant_utils.py:187-198,213): q = clamp(rint(acc*m[c]), lo, hi)
  * with m[c] = mantissa*2^-e as f64; exact_z selects the float32 round trip through sb[c]. */
 int qasr_requant(void* stream, const int32_t* acc, const double* m, const float* sb, int exact_z, int relu,
                  int B, int c, int Tp, int lo, int hi, int8_t* out);
+
+/* ---- dynamic-quantisation device path (QuantAct.forward with dynamic=True, quant_modules.py:149-194) --------------
+ * In dynamic mode every QuantAct takes its range from the batch in front of it, so multipliers, bias integers and
+ * output scales are data dependent.  These entries keep the whole derivation on the device (the reference goes through
+ * host numpy in batch_frexp, quant_utils.py:121-147); qasr/dynamic.py strings them together with the conv accumulator
+ * kernels above into ConvASREncoder / ConvASRDecoder forward passes.  A float tensor is handed over as the integers of
+ * its producer times their float32 scales: */
+typedef struct qasr_dyn_view {
+  const void* data;            /* int32 [B][C][Tp] accumulators, or int8 [B][C][Tp] codes (is_int8) */
+  const float* scale;          /* f32 [C] (per_channel) or [1] */
+  int32_t is_int8, per_channel;
+} qasr_dyn_view;
+/* x_act.min() / .max() (quant_modules.py:152-153): x_act = relu?(a) (+ b as the identity), zero where t >= lens[b]
+ * (MaskedConv1d's mask, jasper.py:177-181; lens NULL: no mask), over t < T.  xf != NULL: the tensor is the float input
+ * itself, [B][C][Tx] (first layer).  minmax: two order-preserving encodings of the float32 min / max. */
+int qasr_dyn_range(void* stream, const qasr_dyn_view* a, const qasr_dyn_view* b, const float* xf, int Tx,
+                   const int32_t* lens, int relu, int B, int C, int T, int Tp, uint32_t* minmax);
+/* act_scaling_factor = max(|min|, |max|, 1e-8) / (2^(bits-1) - 1) (quant_utils.py:44-54) -> s_out[0]; per channel the
+ * fixedpoint_mul multiplier m 2^-e of f64(pre_sf[c]) / f64(act_sf) with (m, e) = batch_frexp (quant_utils.py:121-147,
+ * 190-196) as float64 -> Ma[c] (operand a, scales sa) and Mb[c] (operand b, scales sb; NULL: none). */
+int qasr_dyn_act_params(void* stream, const uint32_t* minmax, int bits, int C, const float* sa, int a_per_channel,
+                        const float* sb, int b_per_channel, float* s_out, double* Ma, double* Mb);
+/* fixedpoint_mul.forward (quant_utils.py:163-216): z = round(relu?(view) / pre_sf) through the float32 view, out =
+ * clamp(round(z_a Ma) (+ round(z_b Mb)), lo, hi) as int8 / uint8 bytes [B][C][Tp]; columns >= min(lens[b], T) are 0. */
+int qasr_dyn_requant(void* stream, const qasr_dyn_view* a, const double* Ma, const qasr_dyn_view* b, const double* Mb,
+                     const int32_t* lens, int relu, int B, int C, int T, int Tp, int lo, int hi, int8_t* out);
+/* first layer (quant_modules.py:180-184): s_out[0] = act_scaling_factor, out = clamp(round(fl32(1/s) x), -n, n-1) */
+int qasr_dyn_quant_in(void* stream, const float* x, int Tx, const uint32_t* minmax, const int32_t* lens, int bits, int B,
+                      int C, int T, int Tp, float* s_out, int8_t* out);
+/* the conv that consumes those codes (quant_modules.py:293-299,307): sf_out[c] = s_w[c] s_x, bias[c] =
+ * clamp(round(fl32(1/sf_out[c]) bprime[c])) evaluated in float32 (+ wsum128[c] = 128 sum(W[c]) when the codes are
+ * stored as u8); rows C..C_pad-1: scale 1, bias 0. */
+int qasr_dyn_conv_params(void* stream, const float* s_x, const float* s_w, const float* bprime, const int32_t* wsum128,
+                         int C, int C_pad, float* sf_out, int32_t* bias);
 
 /* One fused time-channel-separable layer exactly as the engine launches it (k_sep2 / k_sep): depthwise QuantConv1d
  * (K taps, stride 1, 'same' padding) -> QuantAct requant -> 1x1 QuantConv1d [-> residual 1x1 QuantConv1d + res_act] ->
@@ -267,6 +302,9 @@ int qasr_sep_layer(void* stream, const qasr_sep_layer_args* a, char* label, size
 /* Diagnostics: when set to a device buffer of 32 int64, work-group (1,0,0) of every k_sep launch writes s_memtime
  * stamps at its phase boundaries (slot 31 = number of stamps); NULL (default) disables. */
 int qasr_debug_prof(void* dev_buf);
+/* per-work-group timeline of the k_sep2 launches that follow: dev_buf[3 wg .. 3 wg + 2] = {start, end (100 MHz
+ * s_memrealtime), HW_ID | XCC_ID << 32}, wg = blockIdx.y * gridDim.x + blockIdx.x; NULL switches it off */
+int qasr_debug_timeline(void* dev_buf);
 
 const char* qasr_last_error(void);
 const char* qasr_version(void);

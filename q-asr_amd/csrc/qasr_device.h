@@ -19,7 +19,8 @@ __device__ __forceinline__ int requant_clamp(int z, double M, int lo, int hi) {
 }
 // Same result, cheaper on average: fp64 VALU ops issue at ~1/4 rate on gfx950, so the product is first formed in
 // float32 and the fp64 path above only runs when that cannot decide the rounding.
-//   p = fl32(z) * fl32(M):  |p - z*M| <= |z*M| * (2^-23 + 2^-48)  (z < 2^24 exact in f32; two roundings of 2^-24 each).
+//   p = fl32(z) * fl32(M):  |p - z*M| <= |z*M| * (2^-23 + 2^-48)  (|z| < 2^24 exact in f32; two roundings of 2^-24 each;
+//   a batch holding |z| >= 2^24, where the conversion itself rounds, takes the fp64 path).
 //   Inside the target range (|p| <= R = max(|lo|,|hi|) + 1) the error is < R * 1.2e-7, hence r = rint(p) is the exact
 //   answer unless p lies within tau = R * 1.5e-7 of a half-integer (p - r is exact in f32); outside the range both the
 //   exact and the approximate product round beyond lo / hi and the clamp (applied to r, in float) gives the same result.
@@ -38,7 +39,7 @@ __device__ __forceinline__ void requant_batch(int (&q)[N], const int (&z)[N], do
   for (int i = 0; i < N; ++i) {
     const float p = __fmul_rn((float)z[i], Mf);
     r[i] = rintf(p);
-    amb |= requant_ambiguous(p, r[i], tau);
+    amb |= requant_ambiguous(p, r[i], tau) | (__builtin_abs(z[i]) >= (1 << 24));   // (float)z inexact: a third rounding
   }
   if (__builtin_expect(__any(amb), 0)) {
 #pragma unroll
@@ -59,7 +60,7 @@ __device__ __forceinline__ void requant_batch4(int (&q)[N], const int (&z)[N], c
   for (int i = 0; i < N; ++i) {
     const float p = __fmul_rn((float)z[i], (float)M[i / 4]);
     r[i] = rintf(p);
-    amb |= requant_ambiguous(p, r[i], tau);
+    amb |= requant_ambiguous(p, r[i], tau) | (__builtin_abs(z[i]) >= (1 << 24));
   }
   if (__builtin_expect(__any(amb), 0)) {
 #pragma unroll

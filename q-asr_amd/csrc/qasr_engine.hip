@@ -331,6 +331,12 @@ const char* qasr_version(void) { return "qasr-hip 0.1 (gfx950)"; }
 
 int qasr_debug_prof(void* dev_buf) {
   qasr::g_prof = (long long*)dev_buf;
+  qasr::g_prof_mode = 0;
+  return QASR_OK;
+}
+int qasr_debug_timeline(void* dev_buf) {
+  qasr::g_prof = (long long*)dev_buf;
+  qasr::g_prof_mode = dev_buf ? 1 : 0;
   return QASR_OK;
 }
 
@@ -860,8 +866,9 @@ int qasr_pw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t
   return QASR_OK;
 }
 
-int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, int B, int c, int kernel, int kpad,
-                     int stride, int dilation, int padding, int T, int Tp, int T_out, int Tp_out, int32_t* acc) {
+int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, const int32_t* bias, int B, int c,
+                     int kernel, int kpad, int stride, int dilation, int padding, int T, int Tp, int T_out, int Tp_out,
+                     int32_t* acc) {
   if (!x || !w || !acc || kpad % 4 || kpad < kernel || Tp % 64 || Tp_out % 64) return fail(QASR_ERR_ARG, "dw_conv_acc: bad arguments");
   void* z;
   int rc = zero_buf(&z);
@@ -869,8 +876,8 @@ int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t
   DwP p{};
   p.x = x;
   p.w = w;
-  p.bias = (const int32_t*)z;      // raw accumulator of the natural (unbiased) product is requested:
-  p.C = c;                          // callers pass x_unsigned = 0 with s8 data, or pre-biased data
+  p.bias = bias ? bias : (const int32_t*)z;   // u8 data: the caller's bias carries 128 * sum(w)
+  p.C = c;
   p.K = kernel;
   p.kpad = kpad;
   p.stride = stride;

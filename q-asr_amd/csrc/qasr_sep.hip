@@ -6,6 +6,7 @@
 namespace qasr {
 
 long long* g_prof = nullptr;
+int g_prof_mode = 0;
 
 extern template int launch_sep_inst<32, false>(hipStream_t, const SepP&);
 extern template int launch_sep_inst<32, true>(hipStream_t, const SepP&);

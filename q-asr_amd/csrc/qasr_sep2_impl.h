@@ -185,7 +185,10 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   const bool f_relu = flags & QASR_F_RELU;
   const bool f_exact = flags & QASR_F_EXACT_Z;
   const int dw_lo = p.dw_lo, dw_hi = p.dw_hi;
-  const bool stamp = p.prof && blockIdx.x == 0 && blockIdx.y == 1 && tid == 0;
+  const bool stamp = p.prof && p.prof_mode == 0 && blockIdx.x == 0 && blockIdx.y == 1 && tid == 0;
+  const bool tline = p.prof && p.prof_mode == 1 && tid == 0;
+  long long tl_start = 0;
+  if (tline) tl_start = (long long)__builtin_amdgcn_s_memrealtime();
   int nst = 0;
 #define STAMP2() do { if (stamp && nst < 31) p.prof[nst++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   STAMP2();
@@ -575,6 +578,12 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
     STAMP2();
   }
   if (stamp) p.prof[31] = nst;
+  if (tline) {
+    long long* r = p.prof + 3 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
+    r[0] = tl_start;
+    r[1] = (long long)__builtin_amdgcn_s_memrealtime();
+    r[2] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(6164) << 32);   // HW_ID, XCC_ID
+  }
 #undef STAMP2
 }
 
@@ -633,6 +642,7 @@ static int launch_sep2_v(hipStream_t s, const SepP& p) {
   }
   SepP q = p;
   q.prof = g_prof;
+  q.prof_mode = g_prof_mode;
   hipLaunchKernelGGL((k_sep2<K, NG, NGP, NP, DBG, TT>), dim3(p.e.B, p.e.Tp / TT, 1), dim3(SEP2_NT), smem, s, q);
   return QASR_OK;
 }

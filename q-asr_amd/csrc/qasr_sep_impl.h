@@ -716,7 +716,7 @@ static int launch_sep_v(hipStream_t s, const SepP& p) {
   }
   dim3 g(p.e.B, p.e.Tp / TT, 1);
   SepP q = p;
-  q.prof = g_prof;
+  q.prof = g_prof_mode == 0 ? g_prof : nullptr;
   hipLaunchKernelGGL((k_sep<K, DIL, EP, DBG, TT>), g, dim3(SEP_NT), smem, s, q);
   return QASR_OK;
 }

@@ -382,7 +382,7 @@ static void launch_utt_v(hipStream_t s, const SepP& p) {
     attr_set = true;
   }
   SepP q = p;
-  q.prof = g_prof;
+  q.prof = g_prof_mode == 0 ? g_prof : nullptr;
   hipLaunchKernelGGL((k_utt<K, EP, DBG>), dim3(p.e.B), dim3(UT_NT), utt_smem_bytes(p, K), s, q);
 }
 

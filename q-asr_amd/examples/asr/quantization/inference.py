@@ -114,6 +114,9 @@ def main():
         audio_s += float(batch[1].sum()) / 16000.0
     torch.cuda.synchronize()
     wall = time.time() - t0
+    served = type(getattr(asr_model, '_engine', None)).__name__
+    print('path:', {'Engine': 'static integer engine (HIP)', 'DynamicRunner': 'dynamic device path (HIP)'}.get(
+        served, 'host modules'))
     print('WER:', word_error_rate(hypotheses=hyps, references=refs))
     print(f'RTFx (incl. host data loading): {audio_s / max(wall, 1e-9):.1f}  ({audio_s:.1f} s audio in {wall:.2f} s)')
 

@@ -162,6 +162,32 @@ class EncDecCTCModel(nn.Module):
                 return False                                    # BN not folded
         return all(mc.conv.fix_bn and mc.conv.quant_mode == 'symmetric' for mc in self._masked_convs())
 
+    def dynamic_ready(self):
+        """True when every QuantAct is in dynamic mode (qm.set_dynamic, quant_modules.py:149-167) on min / max ranges and
+        the convs are folded and fixed: the configuration qasr.dynamic.DynamicRunner executes on the HIP kernels."""
+        acts = [m for m in self.modules() if isinstance(m, QuantAct)]
+        if not acts or any(a.quant_mode != 'symmetric' or not a.dynamic or a.percentile or a.per_channel for a in acts):
+            return False
+        for blk in self.encoder.encoder_layers:
+            if any(isinstance(l, nn.BatchNorm1d) for l in blk.mconv):
+                return False
+        return all(mc.conv.fix_bn and mc.conv.quant_mode == 'symmetric' for mc in self._masked_convs())
+
+    def _get_dynamic_runner(self, device):
+        """DynamicRunner for the live weights, or None when the topology is outside its scope (dense k>1 convs, several
+        residual panes): those models keep the host modules in dynamic mode."""
+        key = ('dyn', self._quant_version, device.index or 0)
+        if self._engine_key != key:
+            from qasr import dynamic, engine as qengine
+            qengine.load_library()
+            cfg, sd, _, _, wbit, abit = self.export_pack_inputs()
+            try:
+                self._engine = dynamic.DynamicRunner(cfg, sd, wbit, abit, device)
+            except NotImplementedError:
+                self._engine = None
+            self._engine_key = key
+        return self._engine
+
     def export_pack_inputs(self):
         """(ModelCfg, pre-fold NeMo-keyed float state dict, act_min, act_max, wbit, abit) of the live model."""
         cfg = qconfigs.topology_from_config(self.cfg)
@@ -252,6 +278,13 @@ class EncDecCTCModel(nn.Module):
                 processed_signal, processed_signal_length = self._frontend_hip(input_signal, input_signal_length)
             log_probs, tokens, enc_len = eng.forward(processed_signal.float(), processed_signal_length)
             return log_probs, enc_len.long(), tokens.long()
+        if ref.is_cuda and self.dynamic_ready():
+            runner = self._get_dynamic_runner(ref.device)
+            if runner is not None:                               # dynamic-quantisation device path
+                if has_in:
+                    processed_signal, processed_signal_length = self._frontend_hip(input_signal, input_signal_length)
+                out = runner.forward(processed_signal.float(), processed_signal_length)
+                return out['log_probs'], out['enc_len'].long(), out['tokens'].long()
         if has_in:
             processed_signal, processed_signal_length = self.preprocessor(input_signal=input_signal,
                                                                           length=input_signal_length)

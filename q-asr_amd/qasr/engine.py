@@ -14,7 +14,9 @@ SYMBOLS = ['qasr_engine_create', 'qasr_engine_destroy', 'qasr_engine_forward', '
            'qasr_engine_time_ops', 'qasr_engine_run_op', 'qasr_engine_op_label',
            'qasr_frontend_mel', 'qasr_frontend_plan', 'qasr_frontend_mel_planned', 'qasr_frontend_frames',
            'qasr_frontend_workspace_bytes', 'qasr_pw_conv_acc',
-           'qasr_dw_conv_acc', 'qasr_requant', 'qasr_sep_layer', 'qasr_quantile2', 'qasr_quantile_workspace_bytes', 'qasr_debug_prof',
+           'qasr_dw_conv_acc', 'qasr_requant', 'qasr_dyn_range', 'qasr_dyn_act_params', 'qasr_dyn_requant',
+           'qasr_dyn_quant_in', 'qasr_dyn_conv_params', 'qasr_sep_layer', 'qasr_quantile2', 'qasr_quantile_workspace_bytes', 'qasr_debug_prof',
+           'qasr_debug_timeline',
            'qasr_last_error', 'qasr_version']
 
 _lib = None
@@ -69,9 +71,15 @@ def load_library():
     lib.qasr_frontend_workspace_bytes.argtypes = [i32, i32, i32]
     lib.qasr_frontend_workspace_bytes.restype = sz
     lib.qasr_pw_conv_acc.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
-    lib.qasr_dw_conv_acc.argtypes = [vp, vp, i32, vp] + [i32] * 11 + [vp]
+    lib.qasr_dw_conv_acc.argtypes = [vp, vp, i32, vp, vp] + [i32] * 11 + [vp]
     lib.qasr_requant.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.qasr_dyn_range.argtypes = [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]
+    lib.qasr_dyn_act_params.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, vp]
+    lib.qasr_dyn_requant.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.qasr_dyn_quant_in.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.qasr_dyn_conv_params.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.qasr_debug_prof.argtypes = [vp]
+    lib.qasr_debug_timeline.argtypes = [vp]
     lib.qasr_sep_layer.argtypes = [vp, C.POINTER(SepLayerArgs), C.c_char_p, sz]
     lib.qasr_quantile2.argtypes = [vp, vp, sz, C.c_float, C.c_float, vp, vp, sz]
     lib.qasr_quantile_workspace_bytes.argtypes = []
@@ -234,7 +242,7 @@ def dw_conv_acc(x: torch.Tensor, w: torch.Tensor, stride=1, dilation=1, padding=
     wp = torch.zeros(Cc, kp, dtype=torch.int8, device=dev)
     wp[:, :K] = w.to(dev)
     acc = torch.zeros(B, Cc, Tpo, dtype=torch.int32, device=dev)
-    _check(lib.qasr_dw_conv_acc(_stream_ptr(), _ptr(xp), 0, _ptr(wp), B, Cc, K, kp, stride, dilation, padding, T, Tp,
+    _check(lib.qasr_dw_conv_acc(_stream_ptr(), _ptr(xp), 0, _ptr(wp), None, B, Cc, K, kp, stride, dilation, padding, T, Tp,
                                 T_out, Tpo, _ptr(acc)), 'qasr_dw_conv_acc')
     return acc[:, :, :T_out]
 

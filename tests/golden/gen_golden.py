@@ -194,17 +194,18 @@ def checksum(a):
 
 
 def run_net(name, cfg, seed, wbit, abit, percentile, batch, frames, lengths, ncal, cal_batch,
-            full_tensors):
+            full_tensors, dynamic=False):
     sd = synth.make_state_dict(cfg, seed)
     model, blocks = build_reference_model(cfg, sd, wbit, abit, percentile)
-    cal = synth.make_calibration(ncal, cal_batch, cfg.feat_in, frames, seed)
-    qm.calibrate(model)
-    clen = torch.tensor([frames] * cal_batch)
-    for c in cal:
-        o, l, sf = encoder_forward(blocks, torch.from_numpy(c), clen)
-        decoder_forward(model.decoder, o, sf)
+    if not dynamic:
+        cal = synth.make_calibration(ncal, cal_batch, cfg.feat_in, frames, seed)
+        qm.calibrate(model)
+        clen = torch.tensor([frames] * cal_batch)
+        for c in cal:
+            o, l, sf = encoder_forward(blocks, torch.from_numpy(c), clen)
+            decoder_forward(model.decoder, o, sf)
     qm.evaluate(model)
-    qm.set_dynamic(model, False)
+    qm.set_dynamic(model, dynamic)      # inference.py:101; dynamic: every QuantAct ranges over the batch in front of it
 
     x = synth.make_features(batch, cfg.feat_in, frames, seed)
     lens = torch.tensor(lengths)
@@ -218,7 +219,7 @@ def run_net(name, cfg, seed, wbit, abit, percentile, batch, frames, lengths, nca
     out = dict(
         meta=np.array(json.dumps(dict(model=name, seed=seed, wbit=wbit, abit=abit, percentile=percentile,
                                       batch=batch, frames=frames, lengths=list(lengths), ncal=ncal,
-                                      cal_batch=cal_batch, nconv=len(tap.calls)))),
+                                      cal_batch=cal_batch, nconv=len(tap.calls), dynamic=bool(dynamic)))),
         act_min=np.array([float(a.x_min) for a in acts], dtype=np.float32),
         act_max=np.array([float(a.x_max) for a in acts], dtype=np.float32),
         act_sf=np.array([float(a.act_scaling_factor.reshape(-1)[0]) for a in acts], dtype=np.float32),
@@ -425,6 +426,10 @@ if __name__ == '__main__':
         run_net('net_miniq_w8a8_pct', M['MiniQuartzNet'](), 2, 8, 8, 99.9, 3, 96, (96, 64, 33), 3, 4, True)
         run_net('net_miniq_w6a6', M['MiniQuartzNet'](), 3, 6, 6, None, 3, 96, (96, 71, 40), 3, 4, True)
         run_net('net_minij_w8a8', M['MiniJasper'](), 4, 8, 8, None, 3, 96, (96, 80, 37), 3, 4, True)
+    if not which or 'dynamic' in which:
+        run_net('net_miniq_dyn_w8a8', M['MiniQuartzNet'](), 7, 8, 8, None, 3, 96, (96, 71, 40), 0, 0, True, dynamic=True)
+        run_net('net_miniq_dyn_w6a6', M['MiniQuartzNet'](), 8, 6, 6, None, 2, 80, (80, 33), 0, 0, True, dynamic=True)
+        run_net('net_quartznet_dyn_w8a8', M['QuartzNet15x5Base-En'](), 9, 8, 8, None, 2, 64, (64, 41), 0, 0, False, dynamic=True)
     if not which or 'full' in which:
         run_net('net_quartznet_w8a8', M['QuartzNet15x5Base-En'](), 5, 8, 8, 99.996, 2, 64, (64, 41), 2, 2, False)
         run_net('net_quartznet_w6a6', M['QuartzNet15x5Base-En'](), 5, 6, 6, 99.996, 2, 64, (64, 41), 2, 2, False)

@@ -145,3 +145,22 @@ def test_cli_inference_runs(tmp_path):
                           '--weight_bit', '8', '--act_bit', '8'], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'WER:' in out.stdout and 'RTFx' in out.stdout
+
+
+def test_cli_inference_dynamic(tmp_path):
+    """BASELINE.json config 1: inference.py --dynamic, batch size 1 (no calibration data): the dynamic-quantisation
+    device path (qasr.dynamic) serves the forward passes."""
+    man = tmp_path / 'manifest.json'
+    audio = synth.make_audio(2, 20000, seed=2)
+    with open(man, 'w') as f:
+        for i in range(2):
+            p = str(tmp_path / f'd{i}.wav')
+            _write_wav(p, audio[i])
+            f.write(json.dumps(dict(audio_filepath=p, duration=20000 / 16000, text='a b')) + '\n')
+    cli = os.path.join(ROOT, 'q-asr_amd', 'examples', 'asr', 'quantization', 'inference.py')
+    out = subprocess.run([sys.executable, cli, '--asr_model', 'QuartzNet15x5Base-En', '--synthetic_model', '--dataset',
+                          str(man), '--batch_size', '1', '--dynamic', '--weight_bit', '8', '--act_bit', '8'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'WER:' in out.stdout
+    assert 'path: dynamic device path (HIP)' in out.stdout
