@@ -227,32 +227,36 @@ def dominant_kernel_roofline(eng, cfg, meta, ms, B, T):
     return out
 
 
-def pair_timing(lane, roof, ops, reps=20):
-    """The dominant kernel with a second, independent launch of itself in flight (two engines, two HIP streams): a
-    128-frame-tile launch of a 32-utterance batch has 128 work-groups for 256 CUs, so the single-launch figure above
-    leaves half the chip idle by construction; this is the per-launch cost the timed region (4 steps in flight) sees."""
+def in_flight_timing(lane, roof, ops, reps=20):
+    """The dominant kernel the way the timed region runs it: one launch per step in flight, all S of them concurrently
+    (S engines, S HIP streams).  A 128-frame-tile launch of a 32-utterance batch has 64 work-groups for 256 CUs, so the
+    single-launch figure leaves three quarters of the chip idle by construction; elapsed / launches with S streams
+    replaying the kernel is the per-launch cost the chip pays in the timed region."""
     import torch
-    e0, e1 = lane['engs'][:2]
-    s0, s1 = lane['streams'][:2]
-    for e_, s_ in ((e0, s0), (e1, s1)):
+    S = lane['S']
+    for e_, s_ in zip(lane['engs'], lane['streams']):
         for o in ops:
             e_.run_op(o, stream=s_)
     torch.cuda.synchronize()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(2)]
-    ev[0][0].record(s0), ev[1][0].record(s1)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(S)]
+    for k in range(S):
+        ev[k][0].record(lane['streams'][k])
     for _ in range(reps):
         for o in ops:
-            e0.run_op(o, stream=s0)
-            e1.run_op(o, stream=s1)
-    ev[0][1].record(s0), ev[1][1].record(s1)
+            for k in range(S):
+                lane['engs'][k].run_op(o, stream=lane['streams'][k])
+    for k in range(S):
+        ev[k][1].record(lane['streams'][k])
     torch.cuda.synchronize()
-    ms = max(ev[0][0].elapsed_time(ev[0][1]), ev[1][0].elapsed_time(ev[1][1]))
-    t = ms * 1e-3 / (2 * reps * len(ops))                        # s per launch, two streams' launches counted
-    return {'effective_launch_us': 1e6 * t, 'achieved_gb_s': roof['algorithmic_bytes_per_launch'] / t / 1e9,
+    ms = max(ev[k][0].elapsed_time(ev[k][1]) for k in range(S))
+    t = ms * 1e-3 / (S * reps * len(ops))                        # s per launch, all streams' launches counted
+    return {'launches_in_flight': S, 'effective_launch_us': 1e6 * t,
+            'stream_launch_us': 1e3 * ms / (reps * len(ops)),
+            'achieved_gb_s': roof['algorithmic_bytes_per_launch'] / t / 1e9,
             'hbm_frac': roof['algorithmic_bytes_per_launch'] / t / PEAK_HBM,
             'mfma_frac': (roof['mfma_ops_per_launch'] + roof['depthwise_ops_per_launch']) / t / PEAK_INT8_OPS,
-            'timing': f'{reps} x the kernel\'s launches of one step on each of two HIP streams (two engines), HIP events '
-                      'recorded on those streams; elapsed / launches'}
+            'timing': f'{reps} x the kernel\'s launches of one step on each of the {S} HIP streams (one engine each), HIP '
+                      'events recorded on those streams; effective = slowest stream\'s elapsed / all launches'}
 
 
 def build_model(device, model_name, wbit, abit):
@@ -487,7 +491,7 @@ def run(args):
         result['roofline'] = dominant_kernel_roofline(eng, cfg, meta, ms, BATCH, FRAMES // 2)
         dom_ops = result['roofline'].pop('_ops')
         if S > 1:
-            result['roofline']['other']['two_in_flight'] = pair_timing(lane, result['roofline'], dom_ops)
+            result['roofline']['other']['in_flight'] = in_flight_timing(lane, result['roofline'], dom_ops)
         mfma_ops, dw_ops, step_bytes = algorithmic_work(cfg, BATCH, FRAMES // 2)
         # whole-step view (all launches, steps in flight as timed): SURVEY §8d bytes = every conv reads its int8 input
         # once, writes its output once, weights once

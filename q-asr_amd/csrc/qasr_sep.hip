@@ -21,10 +21,14 @@ extern template int launch_sep2_inst<128, true>(hipStream_t, const SepP&);
 
 // k_sep2 takes the stride-1 separable layers it is built for (sep2_shape_ok) unless the engine was told to stay on k_sep
 bool sep2_takes(const SepP& p) { return p.gen == 2 && sep2_shape_ok(p); }
-// frames per work-group of a k_sep2 launch: 128 for plain layers when the engine asks for it (throughput mode: every
-// weight fragment then feeds four frame tiles, B * Tp / 128 work-groups per launch), else the engine's 32 / 64
+// frames per work-group of a k_sep2 launch: 128 for the depthwise-separable layers when the engine asks for it
+// (throughput mode: every weight fragment then feeds four frame tiles, B * Tp / 128 work-groups per launch), else the
+// engine's 32 / 64; the residual layers stay on 64 (0.454 vs 0.462 ms per step with them on 128: twice the work-group
+// time on half the CUs is no gain there) unless QASR_RES_TILE128=1 (A/B runs)
 static int sep2_tile(const SepP& p) {
-  if (p.tile == 128) return (!(p.e.flags & QASR_F_RESADD) && p.K > 0 && p.e.Tp % 128 == 0) ? 128 : 64;
+  static const bool res128 = [] { const char* g = getenv("QASR_RES_TILE128"); return g && atoi(g) != 0; }();
+  if (p.tile == 128)
+    return (p.K > 0 && p.e.Tp % 128 == 0 && (res128 || !(p.e.flags & QASR_F_RESADD))) ? 128 : 64;
   return p.tile == 64 ? 64 : 32;
 }
 

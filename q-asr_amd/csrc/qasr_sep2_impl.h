@@ -652,7 +652,7 @@ template <int TT, bool DBG>
 int launch_sep2_inst(hipStream_t s, const SepP& p) {
   const int ng = p.cin_pad >> 7, ngp = (p.e.flags & QASR_F_RESADD) ? (p.panes[0].cin_pad >> 7) : 0, np = (p.e.cout + 255) / 256;
 #define SEP2_LAUNCH(K_, NG_, NGP_, NP_)                                                  \
-  if constexpr (TT <= 64 || NGP_ == 0) {                                                 \
+  if constexpr (TT <= 64 || K_ > 0) {   /* the bare 1x1 form spills at 128 frames */       \
     if (p.K == K_ && ng == NG_ && ngp == NGP_ && np == NP_) return launch_sep2_v<K_, NG_, NGP_, NP_, DBG, TT>(s, p); \
   }
   SEP2_INSTANCES(SEP2_LAUNCH)
