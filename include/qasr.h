@@ -302,8 +302,9 @@ int qasr_sep_layer(void* stream, const qasr_sep_layer_args* a, char* label, size
 /* Diagnostics: when set to a device buffer of 32 int64, work-group (1,0,0) of every k_sep launch writes s_memtime
  * stamps at its phase boundaries (slot 31 = number of stamps); NULL (default) disables. */
 int qasr_debug_prof(void* dev_buf);
-/* per-work-group timeline of the k_sep2 launches that follow: dev_buf[3 wg .. 3 wg + 2] = {start, end (100 MHz
- * s_memrealtime), HW_ID | XCC_ID << 32}, wg = blockIdx.y * gridDim.x + blockIdx.x; NULL switches it off */
+/* per-work-group timeline of the k_sep2 launches that follow: dev_buf[4 wg .. 4 wg + 3] = {start, end (100 MHz
+ * s_memrealtime), HW_ID | XCC_ID << 32, shader cycles (s_memtime) between the two}, wg = blockIdx.y * gridDim.x +
+ * blockIdx.x; NULL switches it off */
 int qasr_debug_timeline(void* dev_buf);
 
 const char* qasr_last_error(void);

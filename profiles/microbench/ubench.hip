@@ -254,6 +254,53 @@ __global__ void k_mfma16(long long* out, int* sink, int seed) {
   sink[threadIdx.x] = s;
 }
 
+// ---- do VALU instructions overlap a wave's own (and its SIMD partner's) MFMAs?  per loop trip: 8 x 32x32x32 MFMA
+// (4 chains) and / or 16 fp64 requants (MODE 1: MFMA only, 2: requant only, 3: both, one MFMA then two requants;
+// 4: 6 x v_mul_f32 per slot, no MFMA)
+template <int MODE>
+__global__ void k_coissue(long long* out, int* sink, int seed) {
+  v16i c[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) c[i][r] = 0;
+  v4i a = {seed, seed + 1, (int)threadIdx.x, 3}, b = {seed * 3, 5, (int)threadIdx.x * 7, 1};
+  int z[16];
+  float f[6];
+  for (int i = 0; i < 16; ++i) z[i] = seed * 977 + threadIdx.x * 13 + i * 1001;
+  for (int i = 0; i < 6; ++i) f[i] = 1.0f + 0.001f * (threadIdx.x + i);
+  const double M = 1.0 / (3.0 + seed);
+  int acc = 0;
+  long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < LOOPS; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (MODE & 1) c[i & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c[i & 3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MODE == 2 || MODE == 3) {
+#pragma unroll
+        for (int j = 2 * i; j < 2 * i + 2; ++j) {
+          double t = __builtin_fma((double)z[j], M, 6755399441055744.0);
+          int q = __double2loint(t);
+          q = min(max(q, -128), 127);
+          acc += q;
+          z[j] += q + it;
+        }
+      }
+      if (MODE == 4) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) f[j] = f[j] * 1.0001f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) { out[2 * (threadIdx.x >> 6)] = t0; out[2 * (threadIdx.x >> 6) + 1] = t1; }
+  int s = acc;
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) s += c[i][r];
+  for (int i = 0; i < 6; ++i) s += (int)f[i];
+  sink[threadIdx.x] = s;
+}
+
 // ---- LDS store forms: 16 bytes per lane as 16 x ds_write_b8, 4 x b32, 1 x b128 ----------------------------------
 __global__ void k_lds_b8(long long* out, int* sink, int seed) {
   __shared__ volatile unsigned char s[64 * 1024];
@@ -370,6 +417,10 @@ int main() {
   ROW("  4x4x4, 4 chains", k_mfma444_chains<4>, 8);
   ROW("v_mfma_i32_32x32x32_i8", k_mfma32, 8);
   ROW("v_mfma_i32_16x16x64_i8", k_mfma16, 8);
+  ROW("loop trip: 8 MFMA 32x32x32", k_coissue<1>, 1);
+  ROW("loop trip: 16 fp64 requants", k_coissue<2>, 1);
+  ROW("loop trip: both interleaved", k_coissue<3>, 1);
+  ROW("loop trip: 48 v_mul_f32", k_coissue<4>, 1);
   ROW("ds_write_b8 (scatter)", k_lds_b8, 8);
   ROW("ds_write_b32", k_lds_b32, 8);
 

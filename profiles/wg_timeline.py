@@ -34,7 +34,7 @@ for _ in range(3):
     e.forward(x, lens)
 torch.cuda.synchronize()
 lib = engine.load_library()
-buf = torch.zeros(3 * 4096, dtype=torch.int64, device='cuda')
+buf = torch.zeros(4 * 4096, dtype=torch.int64, device='cuda')
 labels = e.op_labels()
 seen = {}
 for oi, lab in enumerate(labels):
@@ -56,7 +56,7 @@ for lab, oi in seen.items():
     e.run_op(oi)                                              # previous launch of the same op just ended: warm caches
     e.run_op(oi)
     torch.cuda.synchronize()
-    st = buf.cpu().numpy().reshape(-1, 3)
+    st = buf.cpu().numpy().reshape(-1, 4)
     st = st[st[:, 1] > 0]
     t0 = st[:, 0].min()
     start, end = (st[:, 0] - t0) / 100.0, (st[:, 1] - t0) / 100.0      # us
@@ -67,6 +67,6 @@ for lab, oi in seen.items():
     slots = len(set(zip(xcc.tolist(), se.tolist(), cu.tolist())))
     print(f'{lab:36s} {len(st):4d} WGs on {slots:3d} (xcc, se, cu) slots | launch {per_launch:6.2f} us (events, back to back) | '
           f'first start -> last end {end.max():6.2f} | starts spread {start.max():5.2f} (p50 {np.median(start):5.2f}) | '
-          f'WG duration min {dur.min():5.2f} p50 {np.median(dur):5.2f} max {dur.max():5.2f}')
+          f'WG duration min {dur.min():5.2f} p50 {np.median(dur):5.2f} max {dur.max():5.2f} | clock {np.median(st[:, 3] / (dur * 1e3)):.2f} GHz')
 lib.qasr_debug_timeline(C.c_void_p(0))
 e.close()

@@ -87,7 +87,7 @@ struct SepP {             // fused separable layer: depthwise stencil -> QuantAc
                           // gen: 2 = route to k_sep2 where it has the shape (engine default), else k_sep
   const int32_t* r32;     // k_utt EP_ADD32: res_act operand rint(acc_res * M_res) of the block's residual conv
   long long* prof;        // diagnostics: s_memtime stamps of work-group (0,0,0), wave 0 (qasr_debug_prof)
-  int prof_mode;          // 1 (qasr_debug_timeline): every work-group writes {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32}
+  int prof_mode;          // 1 (qasr_debug_timeline): every work-group writes {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, shader cycles}
   PaneP panes[QASR_MAX_PANES];
   EpiP e;
 };

@@ -149,6 +149,52 @@ __device__ __forceinline__ void sep2_gemm(v16i (&acc)[MT], v4i (&wf)[16], const 
   }
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void sep2_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sep2_for<I + 1, N>(f);
+  }
+}
+// sep2_gemm with a slice of other work behind every batch of MFMAs: cb(integral_constant<q>), q < 4 N / AB.  The matrix
+// pipe runs a 32x32x32 MFMA for 32 cycles while the wave issues the slice's VALU instructions (the previous unit's
+// requantisation); sched_barrier keeps the compiler from gathering the slices behind the last MFMA.
+template <int MT, int N, int N0, int AB, class CB>
+__device__ __forceinline__ void sep2_gemm_cb(v16i (&acc)[MT], v4i (&wf)[16], const lds_u8* img_lane, int mt_stride,
+                                             const v4i* __restrict__ r0, const v4i* __restrict__ r1, CB&& cb) {
+  constexpr int NQ = 4 * N / AB;
+  v4i a[2][MT][AB];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < AB; ++i) a[0][mt][i] = sep2_a_frag(img_lane + mt * mt_stride, i);
+  sep2_for<0, NQ>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (q + 1 < NQ) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < AB; ++i) a[(q + 1) & 1][mt][i] = sep2_a_frag(img_lane + mt * mt_stride, AB * (q + 1) + i);
+    }
+#pragma unroll
+    for (int i = 0; i < AB; ++i)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q & 1][mt][i], wf[AB * q + i], acc[mt], 0, 0, 0);
+    if constexpr ((AB * (q + 1)) % 4 == 0) {
+      constexpr int g = (AB * (q + 1)) / 4 - 1;
+      if constexpr (g < N0) {
+        if (r0) sep2_load_wg(&wf[4 * g], r0 + 256 * g);
+      } else {
+        if (r1) sep2_load_wg(&wf[4 * g], r1 + 256 * g);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cb(qc);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
 // per-lane (= per output channel, MFMA C layout: channel = lane & 31) parameters of one 256-channel pass
 struct Sep2PassP {
   int bias, pbias;
@@ -187,8 +233,11 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   const int dw_lo = p.dw_lo, dw_hi = p.dw_hi;
   const bool stamp = p.prof && p.prof_mode == 0 && blockIdx.x == 0 && blockIdx.y == 1 && tid == 0;
   const bool tline = p.prof && p.prof_mode == 1 && tid == 0;
-  long long tl_start = 0;
-  if (tline) tl_start = (long long)__builtin_amdgcn_s_memrealtime();
+  long long tl_start = 0, tl_clk = 0;
+  if (tline) {
+    tl_start = (long long)__builtin_amdgcn_s_memrealtime();
+    tl_clk = (long long)__builtin_amdgcn_s_memtime();
+  }
   int nst = 0;
 #define STAMP2() do { if (stamp && nst < 31) p.prof[nst++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   STAMP2();
@@ -453,6 +502,96 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   const bool full_out = t0 + TT <= lim;
   int32_t* const pdbg = RES ? p.panes[0].acc_dbg : nullptr;
   const int qlo = f_relu ? max(e.qlo, 0) : e.qlo, qhi = e.qhi;
+  // Plain layers with one consumer: the requantisation of one unit (half the frame tiles of a pass; the whole pass at
+  // 32 / 64-frame tiles with a single tile per half) runs in slices behind the MFMA batches of the next unit's GEMM -
+  // the epilogue is VALU work (fp64 fma + med3 per value), the GEMM matrix-pipe work, and a work-group's phases are
+  // otherwise serial.  Only the first GEMM unit and the last unit's epilogue stay exposed.
+  constexpr bool PIPED = !RES && (NP * (MT >= 2 ? 2 : 1) > 1);   // (sep2_shape_ok: plain layers have exactly one consumer)
+  if constexpr (PIPED) {
+    {
+      constexpr int MH = MT >= 2 ? MT / 2 : 1, NH = MT / MH, NUN = NP * NH;   // tiles per unit, units per pass, units
+      constexpr int AB = MH >= 2 ? 1 : 2, NQ = 4 * NG / AB, NV = 16 * MH, VPS = (NV + NQ - 1) / NQ;   // (register budget at MH = 2)
+      const OutP& o0 = e.outs[0];
+      const int olo = o0.lo, ohi = o0.hi;
+      int8_t* const optr = (int8_t*)o0.ptr;
+      int rl = lim - t0 - 4 * h;
+      asm volatile("" : "+v"(rl));
+      v16i accs[2][MH];
+      int q4[4];
+      unsigned P[4];
+      // accumulator hooks, masked frames, EXACT_Z of a finished unit (tiles mt0 .. mt0 + MH - 1 of pass ps)
+      auto unit_finish = [&](v16i (&a)[MH], int ps, int mt0) __attribute__((always_inline)) {
+        const int co = 256 * ps + co_l;
+        if (DBG && e.acc_dbg) {
+#pragma unroll
+          for (int mt = 0; mt < MH; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int t = t0 + 32 * (mt0 + mt) + mfma32_row(r, h);
+              if (t < eT) e.acc_dbg[((size_t)b * ecout + co) * eTp + t] = a[mt][r];
+            }
+        }
+        if (!full_out) {
+#pragma unroll
+          for (int mt = 0; mt < MH; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (32 * (mt0 + mt) + (r & 3) + 8 * (r >> 2) >= rl) a[mt][r] = 0;
+        }
+        if (f_exact) {
+          unsigned t = 0;
+#pragma unroll
+          for (int mt = 0; mt < MH; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t |= (unsigned)(a[mt][r] + (1 << 21));
+          if (__any((t >> 22) != 0)) {
+#pragma unroll
+            for (int mt = 0; mt < MH; ++mt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) a[mt][r] = z_roundtrip(a[mt][r], pps[ps].sbm, f_relu);
+          }
+        }
+      };
+      // values [v0, v1) of a finished unit: requantise; a completed tile leaves as one 16-byte store per lane
+      auto unit_values = [&](v16i (&a)[MH], int ps, int mt0, auto v0c, auto v1c) __attribute__((always_inline)) {
+        constexpr int v0 = decltype(v0c)::value, v1 = decltype(v1c)::value;
+        sep2_for<v0, v1>([&](auto vc) {
+          constexpr int v = decltype(vc)::value, mt = v / 16, r = v % 16;
+          q4[r & 3] = rq_clamp(a[mt][r], pps[ps].Mo[0], olo, ohi);
+          if constexpr ((r & 3) == 3) P[r >> 2] = pack4b(q4[0], q4[1], q4[2], q4[3]);
+          if constexpr (r == 15) {
+            const auto s02 = __builtin_amdgcn_permlane32_swap(P[0], P[2], false, false);
+            const auto s13 = __builtin_amdgcn_permlane32_swap(P[1], P[3], false, false);
+            const v4i pk = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+            *(v4i*)(optr + ((size_t)b * ecout + 256 * ps + co_l) * eTp + t0 + 32 * (mt0 + mt) + 16 * h) = pk;
+          }
+        });
+      };
+      sep2_for<0, NUN>([&](auto uc) {
+        constexpr int u = decltype(uc)::value, ps = u / NH, hf = u % NH;
+        v16i (&cur)[MH] = accs[u & 1];
+#pragma unroll
+        for (int mt = 0; mt < MH; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cur[mt][r] = pps[ps].bias;
+        // the slab is re-requested with the next pass's rows of this wave while the pass's last unit multiplies
+        const v4i* const wnext = (hf == NH - 1 && ps + 1 < NP) ? w_frag(p.w, CIN_PAD, 256 * (ps + 1) + co_l, 0) : nullptr;
+        if constexpr (u > 0) unit_finish(accs[(u - 1) & 1], (u - 1) / NH, ((u - 1) % NH) * MH);
+        sep2_gemm_cb<MH, NG, 0, AB>(cur, wf, xd_lane + hf * MH * (CIN_PAD * 32), CIN_PAD * 32, nullptr, wnext, [&](auto qc) {
+          if constexpr (u > 0) {
+            constexpr int q = decltype(qc)::value, v0 = q * VPS < NV ? q * VPS : NV, v1 = (q + 1) * VPS < NV ? (q + 1) * VPS : NV;
+            unit_values(accs[(u - 1) & 1], (u - 1) / NH, ((u - 1) % NH) * MH, std::integral_constant<int, v0>{},
+                        std::integral_constant<int, v1>{});
+          }
+        });
+        STAMP2();
+      });
+      unit_finish(accs[(NUN - 1) & 1], NP - 1, (NH - 1) * MH);
+      unit_values(accs[(NUN - 1) & 1], NP - 1, (NH - 1) * MH, std::integral_constant<int, 0>{}, std::integral_constant<int, NV>{});
+      STAMP2();
+    }
+  }
+  if constexpr (!PIPED) {
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
     const int cbase = 256 * ps;
@@ -577,11 +716,13 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
     }
     STAMP2();
   }
+  }
   if (stamp) p.prof[31] = nst;
   if (tline) {
-    long long* r = p.prof + 3 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
+    long long* r = p.prof + 4 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
     r[0] = tl_start;
     r[1] = (long long)__builtin_amdgcn_s_memrealtime();
+    r[3] = (long long)__builtin_amdgcn_s_memtime() - tl_clk;     // shader cycles of the work-group: / (r[1] - r[0]) = clock / 100 MHz
     r[2] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(6164) << 32);   // HW_ID, XCC_ID
   }
 #undef STAMP2
@@ -617,9 +758,7 @@ static inline bool sep2_shape_ok(const SepP& p) {
     for (int j = 0; j < e.n_outs; ++j)
       if (e.outs[j].mode != 0 && e.outs[j].mode != 2) return false;
   } else {
-    if (p.n_panes != 0) return false;
-    for (int j = 0; j < e.n_outs; ++j)
-      if (e.outs[j].mode != 1) return false;
+    if (p.n_panes != 0 || e.n_outs != 1 || e.outs[0].mode != 1) return false;   // one consumer: the pipelined epilogue
   }
   if (p.cin != p.cin_pad || (e.cout & 255) || (ngp && p.panes[0].cin != p.panes[0].cin_pad)) return false;   // exact shapes
   const int ng = p.cin_pad >> 7, np = (e.cout + 255) / 256;

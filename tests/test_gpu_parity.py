@@ -476,7 +476,9 @@ def test_sep_layer_against_oracle(eng, gen, tile, K, cin, cout, rcin):
     from qasr.pack import F_EXACT_Z, F_MASK_OUT, F_RELU
     for T, big in ((250, False), (301, True)):
         rng = np.random.default_rng(K * 1000 + T + cin + rcin)
-        c = _sep_case(rng, 3, T, cin, cout, K, True, rcin or None, 2, big=big)
+        # consumers: a block-end layer feeds the next block's depthwise conv and residual conv (2); a plain layer has one
+        # (k_sep2's pipelined epilogue is built for exactly that; k_sep takes any number)
+        c = _sep_case(rng, 3, T, cin, cout, K, True, rcin or None, 2 if (rcin or gen == 1) else 1, big=big)
         want = O.sep_layer_ref(c['x'], c['lens'], c['wdw'], c['m_dw'], (-128, 127), c['wpw'], c['bias'], c['outs'], relu=True,
                                mask_out=True, sb=c['sb'], exact_z=big, res=c['res'])
         if big:
