@@ -366,22 +366,28 @@ def test_requant_fast_path_adversarial(eng):
 
 
 # ---------------------------------------------------------------------------------- production shape
-GENERATIONS = [dict(gen=2), dict(gen=2, wide_tiles=True), dict(gen=1), dict(gen=1, wide_tiles=True), dict(gen=1, whole_utterance=True)]
-GEN_IDS = ['k_sep2_32', 'k_sep2_64', 'k_sep_32', 'k_sep_64', 'k_utt']
+GENERATIONS = [dict(gen=2), dict(gen=2, wide_tiles=True, tile128=0), dict(gen=2, wide_tiles=True, tile128=1), dict(gen=1),
+               dict(gen=1, wide_tiles=True), dict(gen=1, whole_utterance=True)]
+GEN_IDS = ['k_sep2_32', 'k_sep2_64', 'k_sep2_128', 'k_sep_32', 'k_sep_64', 'k_utt']
 
 
-def _engine_gen(eng, blob, gen, **kw):
-    """QASR_SEP_GEN is read at engine creation: 1 keeps every separable layer on k_sep, 2 (default) routes the stride-1
-    layers with 256 / 512 input channels to k_sep2."""
-    old = os.environ.get('QASR_SEP_GEN')
-    os.environ['QASR_SEP_GEN'] = str(gen)
+def _engine_gen(eng, blob, gen, tile128=None, **kw):
+    """QASR_SEP_GEN / QASR_TILE128 are read at engine creation: gen 1 keeps every separable layer on k_sep, 2 (default)
+    routes the stride-1 layers with 256 / 512 input channels to k_sep2; with wide tiles, tile128 = 1 puts k_sep2's plain
+    layers (and Jasper's plain dense convs) on 128-frame tiles, 0 keeps everything on 64."""
+    env = {'QASR_SEP_GEN': str(gen)}
+    if tile128 is not None:
+        env['QASR_TILE128'] = str(tile128)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         return eng.Engine(blob, 0, **kw)
     finally:
-        if old is None:
-            del os.environ['QASR_SEP_GEN']
-        else:
-            os.environ['QASR_SEP_GEN'] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
 @pytest.fixture(scope='module')
@@ -412,6 +418,8 @@ def test_quartznet_t500_every_accumulator(eng, oracle_quartznet_t500, family):
     labels = e.op_labels()
     if family.get('gen') == 2:
         assert sum(l.startswith('k_sep2<') for l in labels) >= 70, labels      # the new kernel is what runs
+        want_tt = '128>' if family.get('tile128') == 1 else ('64>' if family.get('wide_tiles') else '32>')
+        assert sum(l.startswith('k_sep2<') and l.endswith(want_tt) for l in labels) >= 50, (want_tt, labels)
     else:
         assert not any(l.startswith('k_sep2<') for l in labels)
     for i, (op, pane) in enumerate(o['pm']['sites']):
@@ -424,6 +432,74 @@ def test_quartznet_t500_every_accumulator(eng, oracle_quartznet_t500, family):
         n = int(want['enc_len'][b])
         assert np.array_equal(tokens.cpu().numpy()[b, :n], want['tokens'][b, :n])
         np.testing.assert_allclose(logp.cpu().numpy()[b, :n], want['log_probs'][b, :n], rtol=1e-4, atol=5e-5)
+    e.close()
+
+
+@pytest.fixture(scope='module')
+def oracle_jasper_t300(golden_dir):
+    """OracleNet on one utterance x 300 frames of Jasper10x5dr w8a8 (150 frames after block 0: 5 / 3 / 2 time tiles)."""
+    d, meta = _load(golden_dir, 'net_jasper_w8a8')
+    cfg = topology.jasper10x5dr()
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    net = O.OracleNet(topology.conv_plan(cfg), cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    x = synth.make_features(1, 64, 300, 4)
+    want = net.forward(x, [300])
+    blob, pm = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    return dict(x=x, want=want, accs=[t['acc'] for t in net.trace], blob=blob, pm=pm, cfg=cfg)
+
+
+@pytest.mark.parametrize('family', [dict(gen=2), dict(gen=2, wide_tiles=True, tile128=0), dict(gen=2, wide_tiles=True, tile128=1)],
+                         ids=['tiles32', 'tiles64', 'tiles128'])
+def test_jasper_t300_every_accumulator(eng, oracle_jasper_t300, family):
+    """Jasper10x5dr's dense convs (tap-shifted GEMMs over a staged window), dense residual panes and many-consumer
+    requants at a production frame count: EVERY conv accumulator (108 convs + decoder) against the CPU oracle, for the
+    three tile sizes the engine uses (32: one step in flight; 64 / 128: throughput mode)."""
+    o = oracle_jasper_t300
+    fam = dict(family)
+    e = _engine_gen(eng, o['blob'], fam.pop('gen'), debug=True, **fam)
+    logp, tokens, enc_len = e.forward(torch.from_numpy(o['x']).cuda(), torch.tensor([300]))
+    torch.cuda.synchronize()
+    couts = _site_dims(o['cfg'])
+    labels = e.op_labels()
+    for i, (op, pane) in enumerate(o['pm']['sites']):
+        want = o['accs'][i]
+        got = e.read_acc(op, pane, couts[i], want.shape[2])
+        assert np.array_equal(got, want), f'conv {i} (op {op}, pane {pane}, {labels[op]})'
+    want = o['want']
+    n = int(want['enc_len'][0])
+    assert np.array_equal(enc_len.cpu().numpy(), want['enc_len'])
+    assert np.array_equal(tokens.cpu().numpy()[0, :n], want['tokens'][0, :n])
+    np.testing.assert_allclose(logp.cpu().numpy()[0, :n], want['log_probs'][0, :n], rtol=1e-4, atol=5e-5)
+    e.close()
+
+
+def test_jasper_bench_size_properties(eng, oracle_jasper_t300):
+    """BASELINE config 4 (Jasper10x5dr w8a8, B = 64, T = 500): size-independent properties at full size - re-running is
+    bit-reproducible, the three tile sizes produce identical integers, an utterance's result does not depend on its batch
+    neighbours or on batch padding."""
+    blob = oracle_jasper_t300['blob']
+    B, T = 64, 500
+    x = torch.from_numpy(synth.make_features(B, 64, T, 12)).cuda()
+    lens = torch.tensor([T - 11 * (i % 7) for i in range(B)])
+    e = _engine_gen(eng, blob, 2)
+    lp1, tk1, el1 = e.forward(x, lens)
+    lp1, tk1, el1 = lp1.cpu().numpy(), tk1.cpu().numpy(), el1.cpu().numpy()
+    lp2, tk2, _ = e.forward(x, lens)
+    assert np.array_equal(tk1, tk2.cpu().numpy()) and np.array_equal(lp1, lp2.cpu().numpy())
+    assert np.array_equal(el1, (lens.numpy() + 1) // 2)
+    for t128 in (0, 1):
+        ew = _engine_gen(eng, blob, 2, wide_tiles=True, tile128=t128)
+        lpw, tkw, _ = ew.forward(x, lens)
+        assert np.array_equal(tk1, tkw.cpu().numpy()) and np.array_equal(lp1, lpw.cpu().numpy()), t128
+        ew.close()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))
+    _, tk3, _ = e.forward(x[perm].contiguous(), lens[perm])
+    assert np.array_equal(tk3.cpu().numpy(), tk1[perm.numpy()])
+    i, L = 9, int(lens[9])
+    lp4, tk4, el4 = e.forward(x[i:i + 1, :, :L].contiguous(), lens[i:i + 1])
+    n = int(el4[0])
+    assert np.array_equal(tk4.cpu().numpy()[0, :n], tk1[i, :n])
+    np.testing.assert_array_equal(lp4.cpu().numpy()[0, :n], lp1[i, :n])
     e.close()
 
 
