@@ -94,6 +94,8 @@ struct qasr_engine {
   bool legacy_pw = false;              // QASR_LEGACY_PW=1: stand-alone 1x1 convs through the v1 kernel k_pw
   std::vector<int> fused_dw;           // per op: index of the DW op fused into this PW op, or -1
   std::vector<char> skip;              // per op: launched as part of the following op
+  bool fuse_dec = true;                // decoder conv + log-softmax + argmax in one launch (QASR_NO_FUSE_DEC=1: two launches)
+  std::vector<char> dec_skip;          // per op: LOGSOFTMAX op that ran inside the preceding decoder launch
   bool tile128 = true;                 // QASR_TILE128=0: k_sep2's plain layers stay on 64-frame tiles in throughput mode (A/B runs)
   bool dense_tile128 = true;           // QASR_DENSE_TILE128=0 keeps Jasper's dense convs on 64-frame tiles (A/B runs)
   bool wide_tiles = false;             // k_sep with 64-frame tiles (throughput mode: bit 3 of `debug`, or QASR_WIDE_TILES=1)
@@ -165,6 +167,7 @@ static int build_plan(qasr_engine* e, int B, int T0) {
   // fusion plan first: it moves the point where a depthwise input is read to the following launch
   e->fused_dw.assign(h.n_ops, -1);
   e->skip.assign(h.n_ops, 0);
+  e->dec_skip.assign(h.n_ops, 0);
   if (e->fuse)
     for (uint32_t oi = 0; oi + 1 < h.n_ops; ++oi) {
       const qasr_op_desc& d = e->ops[oi];
@@ -359,6 +362,7 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
   e->fuse = getenv("QASR_NO_FUSE") == nullptr;
   e->legacy_pw = getenv("QASR_LEGACY_PW") != nullptr;
   if (const char* g = getenv("QASR_TILE128")) e->tile128 = atoi(g) != 0;
+  if (const char* g = getenv("QASR_NO_FUSE_DEC")) e->fuse_dec = atoi(g) == 0;
   if (const char* g = getenv("QASR_DENSE_TILE128")) e->dense_tile128 = atoi(g) != 0;
   if (const char* g = getenv("QASR_SEP_GEN")) e->sep_gen = atoi(g) == 1 ? 1 : 2;
   // whole-utterance kernels (k_utt) are opt-in: bit 2 of `debug` or QASR_UTT=1 (throughput experiments)
@@ -559,6 +563,13 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
       if (!e->legacy_pw || e->fused_dw[oi] >= 0) {
         SepP p{};
         build_sep(e, oi, p);
+        if (e->fuse_dec && (op.flags & QASR_F_LOGITS) && oi + 1 < e->h.n_ops && e->ops[oi + 1].kind == QASR_OP_LOGSOFTMAX &&
+            e->ops[oi + 1].in == op.outs[0].tensor && decoder_fusable(p)) {
+          int rc = launch_decoder(s, p, logp, tokens, lens_out, e->debug);
+          if (rc) return fail(rc, "op %u: decoder launch", oi);
+          e->dec_skip[oi + 1] = 1;
+          break;
+        }
         if (e->utt[oi] == 1) {
           launch_utt(s, p, 0);
         } else if (e->utt[oi] == 2) {
@@ -648,6 +659,7 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
       break;
     }
     case QASR_OP_LOGSOFTMAX: {
+      if (e->dec_skip[oi]) break;                            // ran inside the decoder's launch (k_dec), lengths included
       launch_logsoftmax(s, (const float*)tin.ptr, logp, tokens, B * tin.T, (int)op.cin);
       if (lens_out)
         HIPCHK(hipMemcpyAsync(lens_out, e->lens_all + (size_t)tin.d.domain * B, sizeof(int32_t) * B,
@@ -753,6 +765,7 @@ int qasr_engine_op_label(qasr_engine* e, int op, char* buf, size_t cap) {
   const qasr_op_desc& d = e->ops[op];
   const char* name = "?";
   if (e->skip[op]) name = "(fused into the next op)";
+  else if (e->dec_skip[op]) name = "(fused into the previous op)";
   else switch (d.kind) {
     case QASR_OP_QUANT_IN: name = "k_quant_in"; break;
     case QASR_OP_DW: name = "k_dw"; break;
@@ -777,6 +790,10 @@ int qasr_engine_op_label(qasr_engine* e, int op, char* buf, size_t cap) {
       {
         SepP p{};
         build_sep(e, (uint32_t)op, p);
+        if (e->fuse_dec && (d.flags & QASR_F_LOGITS) && op + 1 < (int)e->h.n_ops && e->dec_skip[op + 1]) {
+          name = "k_dec";
+          break;
+        }
         sep_kernel_label(p, buf, cap);
         return QASR_OK;
       }
