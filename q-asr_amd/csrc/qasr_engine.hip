@@ -94,6 +94,9 @@ struct qasr_engine {
   bool legacy_pw = false;              // QASR_LEGACY_PW=1: stand-alone 1x1 convs through the v1 kernel k_pw
   std::vector<int> fused_dw;           // per op: index of the DW op fused into this PW op, or -1
   std::vector<char> skip;              // per op: launched as part of the following op
+  bool fuse_stem = true;               // block 0 (lengths, first-layer quantisation, strided depthwise, 1x1) in one launch (QASR_NO_FUSE_STEM=1: four)
+  bool stem = false;                   // ... and the plan has that shape: ops 0..2 run as k_stem
+  const int32_t* cur_lens = nullptr;   // the caller's lengths of the current / last forward (k_stem derives every domain's from them)
   bool fuse_dec = true;                // decoder conv + log-softmax + argmax in one launch (QASR_NO_FUSE_DEC=1: two launches)
   std::vector<char> dec_skip;          // per op: LOGSOFTMAX op that ran inside the preceding decoder launch
   bool tile128 = true;                 // QASR_TILE128=0: k_sep2's plain layers stay on 64-frame tiles in throughput mode (A/B runs)
@@ -363,6 +366,7 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
   e->legacy_pw = getenv("QASR_LEGACY_PW") != nullptr;
   if (const char* g = getenv("QASR_TILE128")) e->tile128 = atoi(g) != 0;
   if (const char* g = getenv("QASR_NO_FUSE_DEC")) e->fuse_dec = atoi(g) == 0;
+  if (const char* g = getenv("QASR_NO_FUSE_STEM")) e->fuse_stem = atoi(g) == 0;
   if (const char* g = getenv("QASR_DENSE_TILE128")) e->dense_tile128 = atoi(g) != 0;
   if (const char* g = getenv("QASR_SEP_GEN")) e->sep_gen = atoi(g) == 1 ? 1 : 2;
   // whole-utterance kernels (k_utt) are opt-in: bit 2 of `debug` or QASR_UTT=1 (throughput experiments)
@@ -519,43 +523,86 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
   }
 }
 
+static void build_quant_in(const qasr_engine* e, uint32_t oi, QuantInP& p) {
+  const qasr_op_desc& op = e->ops[oi];
+  const TensorRT& tin = e->tens[op.in];
+  const TensorRT& to = e->tens[op.outs[0].tensor];
+  p.x = (const float*)tin.ptr;
+  p.out = (int8_t*)to.ptr;
+  p.lens = e->lens_all + (size_t)to.d.domain * e->B;
+  p.inv_scale = op.in_inv_scale;
+  p.lo = op.qlo;
+  p.hi = op.qhi;
+  p.C = (int)op.cin;
+  p.T = tin.T;
+  p.Tp = to.Tp;
+  p.B = e->B;
+}
+static void build_dw(qasr_engine* e, uint32_t oi, DwP& p) {
+  const qasr_op_desc& op = e->ops[oi];
+  const TensorRT& tin = e->tens[op.in];
+  p.x = (const int8_t*)tin.ptr;
+  p.w = dev_w(e, op.w_off);
+  p.bias = dev_at<int32_t>(e, op.bias_off);
+  p.C = (int)op.cin;
+  p.K = (int)op.kernel;
+  p.kpad = rup(p.K, 4);
+  p.stride = (int)op.stride;
+  p.dilation = (int)op.dilation;
+  p.padding = (int)op.padding;
+  p.T_in = tin.T;
+  p.Tp_in = tin.Tp;
+  p.x_unsigned = tin.d.dtype == QASR_DT_U8;
+  fill_epi(e, oi, op, p.e);
+}
+// ops 0..2 = [first-layer QuantAct, strided depthwise conv, 1x1 conv], each feeding only the next: the stem k_stem runs
+static bool stem_shape(qasr_engine* e) {
+  if (e->h.n_ops < 3 || e->use_utt) return false;
+  const qasr_op_desc &a = e->ops[0], &b = e->ops[1], &c = e->ops[2];
+  if (a.kind != QASR_OP_QUANT_IN || b.kind != QASR_OP_DW || c.kind != QASR_OP_PW || e->skip[1] || e->fused_dw[2] >= 0) return false;
+  if (b.in != a.outs[0].tensor || c.in != b.outs[0].tensor || a.outs[1].tensor >= 0 || b.outs[1].tensor >= 0) return false;
+  for (uint32_t oi = 3; oi < e->h.n_ops; ++oi) {             // nobody else reads the two intermediate tensors
+    const qasr_op_desc& q = e->ops[oi];
+    if (q.in == a.outs[0].tensor || q.in == b.outs[0].tensor) return false;
+    for (uint32_t k = 0; k < q.n_panes; ++k)
+      if (q.panes[k].in == a.outs[0].tensor || q.panes[k].in == b.outs[0].tensor) return false;
+  }
+  QuantInP qi{};
+  DwP dw{};
+  SepP pw{};
+  build_quant_in(e, 0, qi);
+  build_dw(e, 1, dw);
+  build_sep(e, 2, pw);
+  return stem_supported(qi, dw, pw);
+}
+static int stem_launch(qasr_engine* e, hipStream_t s) {
+  QuantInP qi{};
+  DwP dw{};
+  SepP pw{};
+  build_quant_in(e, 0, qi);
+  build_dw(e, 1, dw);
+  build_sep(e, 2, pw);
+  int rc = launch_stem(s, qi, dw, pw, (const qasr_domain_desc*)(e->dblob + e->h.domains_off), (int)e->h.n_domains, e->cur_lens,
+                       e->lens_all);
+  return rc ? fail(rc, "k_stem launch") : QASR_OK;
+}
+
 static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, int32_t* tokens, int32_t* lens_out) {
   const qasr_op_desc& op = e->ops[oi];
   const int B = e->B;
   if (e->skip[oi]) return QASR_OK;        // runs inside the next op's k_sep launch
+  if (e->stem && oi <= 2) return oi == 0 ? stem_launch(e, s) : QASR_OK;   // block 0 as one launch
   const TensorRT& tin = e->tens[op.in];
   switch (op.kind) {
     case QASR_OP_QUANT_IN: {
-      const TensorRT& to = e->tens[op.outs[0].tensor];
       QuantInP p{};
-      p.x = (const float*)tin.ptr;
-      p.out = (int8_t*)to.ptr;
-      p.lens = e->lens_all + (size_t)to.d.domain * B;
-      p.inv_scale = op.in_inv_scale;
-      p.lo = op.qlo;
-      p.hi = op.qhi;
-      p.C = (int)op.cin;
-      p.T = tin.T;
-      p.Tp = to.Tp;
-      p.B = B;
+      build_quant_in(e, oi, p);
       launch_quant_in(s, p);
       break;
     }
     case QASR_OP_DW: {
       DwP p{};
-      p.x = (const int8_t*)tin.ptr;
-      p.w = dev_w(e, op.w_off);
-      p.bias = dev_at<int32_t>(e, op.bias_off);
-      p.C = (int)op.cin;
-      p.K = (int)op.kernel;
-      p.kpad = rup(p.K, 4);
-      p.stride = (int)op.stride;
-      p.dilation = (int)op.dilation;
-      p.padding = (int)op.padding;
-      p.T_in = tin.T;
-      p.Tp_in = tin.Tp;
-      p.x_unsigned = tin.d.dtype == QASR_DT_U8;
-      fill_epi(e, oi, op, p.e);
+      build_dw(e, oi, p);
       launch_dw(s, p);
       break;
     }
@@ -685,9 +732,11 @@ int qasr_engine_forward(qasr_engine* e, void* stream, const float* feats, const 
   }
   const auto& h = e->h;
   e->tens[0].ptr = (void*)feats;
+  e->cur_lens = lens;
+  e->stem = e->fuse_stem && stem_shape(e);
   auto enqueue = [&]() -> int {
     const qasr_domain_desc* ddoms = (const qasr_domain_desc*)(e->dblob + h.domains_off);
-    launch_lens(s, lens, e->lens_all, ddoms, (int)h.n_domains, B);
+    if (!e->stem) launch_lens(s, lens, e->lens_all, ddoms, (int)h.n_domains, B);   // (k_stem derives them itself)
     for (uint32_t oi = 0; oi < h.n_ops; ++oi) {
       if (e->timing) HIPCHK(hipEventRecord(e->ev[oi], s));
       int rc = launch_op(e, s, oi, logp, tokens, lens_out);
@@ -766,6 +815,7 @@ int qasr_engine_op_label(qasr_engine* e, int op, char* buf, size_t cap) {
   const char* name = "?";
   if (e->skip[op]) name = "(fused into the next op)";
   else if (e->dec_skip[op]) name = "(fused into the previous op)";
+  else if (e->stem && op <= 2) name = op == 0 ? "k_stem" : "(fused into the first op)";
   else switch (d.kind) {
     case QASR_OP_QUANT_IN: name = "k_quant_in"; break;
     case QASR_OP_DW: name = "k_dw"; break;

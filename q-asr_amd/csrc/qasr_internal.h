@@ -125,6 +125,10 @@ bool utt_supported(int K, int dilation, int Tp, int cin_pad, int cin);
 void launch_utt(hipStream_t s, const SepP& p, int ep);   // ep: 0 plain, 1 rq32 (residual conv), 2 add32 (res_act)
 void launch_requant(hipStream_t s, const RequantP& p);
 void launch_logsoftmax(hipStream_t s, const float* logits, float* logp, int32_t* tokens, int rows, int ncls);
+// qasr_stem.hip: lengths + first-layer QuantAct + strided depthwise conv + 1x1 conv of block 0 as one launch
+bool stem_supported(const QuantInP& qi, const DwP& dw, const SepP& pw);
+int launch_stem(hipStream_t s, const QuantInP& qi, const DwP& dw, const SepP& pw, const qasr_domain_desc* doms, int n_domains,
+                const int32_t* lens_in, int32_t* lens_all);
 // qasr_decoder.hip: the decoder's 1x1 conv + log_softmax + argmax (+ the encoded lengths) as one launch
 bool decoder_fusable(const SepP& p);
 int launch_decoder(hipStream_t s, const SepP& p, float* logp, int32_t* tokens, int32_t* lens_out, bool keep_logits);
