@@ -210,6 +210,35 @@ def test_bench_size_properties(eng, golden_dir):
     e.close()
 
 
+def test_fused_stem_and_decoder_match_unfused(eng, golden_dir):
+    """k_stem (lengths + first-layer quantisation + strided depthwise + 1x1 conv of block 0) and k_dec (decoder conv +
+    log-softmax + argmax + lengths) against the four- / two-launch forms they replace: identical log-probs, tokens and
+    lengths at bench size with ragged lengths, and the labels say which form ran."""
+    d, meta = _load(golden_dir, 'net_quartznet_w8a8')
+    cfg = topology.quartznet15x5()
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    blob, _ = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    B, T = 32, 500
+    x = torch.from_numpy(synth.make_features(B, 64, T, 13)).cuda()
+    lens = torch.tensor([T - 13 * (i % 11) for i in range(B)])
+    outs = []
+    for stem, dec in ((1, 1), (0, 0)):
+        os.environ['QASR_NO_FUSE_STEM'], os.environ['QASR_NO_FUSE_DEC'] = str(1 - stem), str(1 - dec)
+        try:
+            e = eng.Engine(blob, 0)
+        finally:
+            del os.environ['QASR_NO_FUSE_STEM'], os.environ['QASR_NO_FUSE_DEC']
+        lp, tk, el = e.forward(x, lens)
+        labels = e.op_labels()
+        assert ('k_stem' in labels) == bool(stem) and ('k_dec' in labels) == bool(dec), labels[:4] + labels[-3:]
+        assert ('k_quant_in' in labels) != bool(stem) and ('k_logsoftmax' in labels) != bool(dec)
+        outs.append((lp.cpu().numpy(), tk.cpu().numpy(), el.cpu().numpy()))
+        e.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(outs[0][2], (lens.numpy() + 1) // 2)
+
+
 def test_steps_in_flight_match_serial(eng, golden_dir):
     """bench.py keeps several steps in flight (one engine + HIP stream each): kernels of different steps interleave on
     the CUs, which exposes any tensor whose arena slot is recycled before its last reader (the halo reads of a fused
