@@ -98,6 +98,7 @@ struct qasr_engine {
   bool stem = false;                   // ... and the plan has that shape: ops 0..2 run as k_stem
   const int32_t* cur_lens = nullptr;   // the caller's lengths of the current / last forward (k_stem derives every domain's from them)
   bool fuse_dec = true;                // decoder conv + log-softmax + argmax in one launch (QASR_NO_FUSE_DEC=1: two launches)
+  std::vector<char> rq_skip;           // per op: REQUANT op served by the launch of an earlier REQUANT op of the same stored value
   std::vector<char> dec_skip;          // per op: LOGSOFTMAX op that ran inside the preceding decoder launch
   bool tile128 = true;                 // QASR_TILE128=0: k_sep2's plain layers stay on 64-frame tiles in throughput mode (A/B runs)
   bool dense_tile128 = true;           // QASR_DENSE_TILE128=0 keeps Jasper's dense convs on 64-frame tiles (A/B runs)
@@ -171,6 +172,7 @@ static int build_plan(qasr_engine* e, int B, int T0) {
   e->fused_dw.assign(h.n_ops, -1);
   e->skip.assign(h.n_ops, 0);
   e->dec_skip.assign(h.n_ops, 0);
+  e->rq_skip.assign(h.n_ops, 0);
   if (e->fuse)
     for (uint32_t oi = 0; oi + 1 < h.n_ops; ++oi) {
       const qasr_op_desc& d = e->ops[oi];
@@ -690,11 +692,22 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
       break;
     }
     case QASR_OP_REQUANT: {
+      if (e->rq_skip[oi]) break;                             // served by an earlier launch on the same stored value
       const TensorRT& to = e->tens[op.outs[0].tensor];
       RequantP p{};
       p.in = tin.ptr;
       p.in_is_i32 = tin.d.dtype == QASR_DT_I32;
-      fill_out(e, op.outs[0], p.out);
+      fill_out(e, op.outs[0], p.outs[0]);
+      p.n_outs = 1;
+      // the packer emits the REQUANT ops of one stored value back to back: one launch serves up to QASR_RQ_MAX of them
+      for (uint32_t oj = oi + 1; oj < e->h.n_ops && p.n_outs < QASR_RQ_MAX; ++oj) {
+        const qasr_op_desc& q = e->ops[oj];
+        if (q.kind != QASR_OP_REQUANT || q.in != op.in || q.flags != op.flags || q.sb_off != op.sb_off || q.cin != op.cin ||
+            e->tens[q.outs[0].tensor].d.domain != to.d.domain)
+          break;
+        fill_out(e, q.outs[0], p.outs[p.n_outs++]);
+        e->rq_skip[oj] = 1;
+      }
       p.sb = dev_at<float>(e, op.sb_off);
       p.lens = e->lens_all + (size_t)to.d.domain * B;
       p.flags = op.flags & QASR_F_MASK_OUT;   // the stored value is already ReLU'd / round-tripped z
@@ -815,6 +828,7 @@ int qasr_engine_op_label(qasr_engine* e, int op, char* buf, size_t cap) {
   const char* name = "?";
   if (e->skip[op]) name = "(fused into the next op)";
   else if (e->dec_skip[op]) name = "(fused into the previous op)";
+  else if (e->rq_skip[op]) name = "(served by the previous k_requant launch)";
   else if (e->stem && op <= 2) name = op == 0 ? "k_stem" : "(fused into the first op)";
   else switch (d.kind) {
     case QASR_OP_QUANT_IN: name = "k_quant_in"; break;
@@ -1038,11 +1052,12 @@ int qasr_requant(void* stream, const int32_t* acc, const double* m, const float*
   RequantP p{};
   p.in = acc;
   p.in_is_i32 = 1;
-  p.out.ptr = out;
-  p.out.mtab = m;
-  p.out.lo = lo;
-  p.out.hi = hi;
-  p.out.mode = 1;
+  p.n_outs = 1;
+  p.outs[0].ptr = out;
+  p.outs[0].mtab = m;
+  p.outs[0].lo = lo;
+  p.outs[0].hi = hi;
+  p.outs[0].mode = 1;
   p.sb = sb;
   p.flags = (exact_z ? QASR_F_EXACT_Z : 0) | (relu ? QASR_F_RELU : 0);
   p.C = c;

@@ -103,10 +103,11 @@ struct QuantInP {
   int lo, hi, C, T, Tp, B;
 };
 
-struct RequantP {         // stand-alone requant of a stored value
+#define QASR_RQ_MAX 8      /* consumers one k_requant launch serves (Jasper's dense residual: up to 11 per stored value) */
+struct RequantP {         // stand-alone requant of a stored value towards n_outs consumers (read once)
   const void* in;         // i32 or s8 [B][C][Tp]
-  int in_is_i32;
-  OutP out;
+  int in_is_i32, n_outs;
+  OutP outs[QASR_RQ_MAX];
   const float* sb;
   const int32_t* lens;
   unsigned flags;

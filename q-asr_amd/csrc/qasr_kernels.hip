@@ -538,7 +538,8 @@ void launch_dense(hipStream_t s, const DenseP& p) {
 
 // ------------------------------------------------------------------------------------------------ requant (stand-alone)
 // One lane = 16 consecutive frames of one (utterance, channel) row: wide loads, the production requant_batch
-// (float32 fast path + fp64 fallback), one 16-byte store.
+// (float32 fast path + fp64 fallback), one 16-byte store per consumer (up to QASR_RQ_MAX consumers per launch: Jasper's
+// dense-residual values feed up to 11 QuantActs, and the stored value is read once for all of them).
 __global__ void __launch_bounds__(256) k_requant(RequantP p) {
   const int tq = blockIdx.x * blockDim.x + threadIdx.x;      // 16-frame group along time
   const int row = blockIdx.y;                                 // b * C + c
@@ -567,23 +568,26 @@ __global__ void __launch_bounds__(256) k_requant(RequantP p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) z[i] = relu ? max(acc[i], 0) : acc[i];
   }
-  int q[16];
-  if (p.out.mode == 2) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) q[i] = z[i];
-  } else {
-    requant_batch<16>(q, z, p.out.mode == 1 ? p.out.mtab[c] : p.out.m, p.out.lo, p.out.hi);
-  }
   const int lim = (p.flags & QASR_F_MASK_OUT) ? min(p.T, p.lens[b]) : p.T;
-  v4i pk;
+  for (int j = 0; j < p.n_outs; ++j) {                        // the stored value is read once for all its consumers
+    const OutP& o = p.outs[j];
+    int q[16];
+    if (o.mode == 2) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    int v[4];
+      for (int i = 0; i < 16; ++i) q[i] = z[i];
+    } else {
+      requant_batch<16>(q, z, o.mode == 1 ? o.mtab[c] : o.m, o.lo, o.hi);
+    }
+    v4i pk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (16 * tq + 4 * g + i < lim) ? q[4 * g + i] : 0;
-    pk[g] = (int)pack4(v[0], v[1], v[2], v[3]);
+    for (int g = 0; g < 4; ++g) {
+      int v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = (16 * tq + 4 * g + i < lim) ? q[4 * g + i] : 0;
+      pk[g] = (int)pack4(v[0], v[1], v[2], v[3]);
+    }
+    *(v4i*)((int8_t*)o.ptr + idx) = pk;
   }
-  *(v4i*)((int8_t*)p.out.ptr + idx) = pk;
 }
 void launch_requant(hipStream_t s, const RequantP& p) {
   dim3 g((p.Tp / 16 + 63) / 64, p.B * p.C);
