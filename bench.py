@@ -398,8 +398,13 @@ def run(args):
         with torch.cuda.stream(lane['streams'][k]):
             if b['gathered'] is not None:                    # the gather of this buffer set's previous step read `tokens`
                 lane['streams'][k].wait_event(b['gathered'])
-            feats, flen = engine.frontend_mel(lane['audio'][k], alen, fb, window, 0.97, 16, out=b['fe'], plan=fe_plan)
-            _, tokens, _ = lane['engs'][k].forward(feats, flen, want_logp=False, out=b['out'])
+            if os.environ.get('QASR_BENCH_SPLIT_FE'):            # (A/B) front-end as its own two launches in front of the graph
+                feats, flen = engine.frontend_mel(lane['audio'][k], alen, fb, window, 0.97, 16, out=b['fe'], plan=fe_plan)
+                _, tokens, _ = lane['engs'][k].forward(feats, flen, want_logp=False, out=b['out'])
+            else:
+              # mel front-end + encoder + decoder as one engine call (one hipGraph launch per step)
+              _, tokens, _ = lane['engs'][k].forward_audio(lane['audio'][k], alen, fb, window, fe_plan, 0.97, 16, want_logp=False,
+                                                         feats=b['fe'][0], feat_lens=b['fe'][1], out=b['out'])
             done = torch.cuda.Event()
             done.record(lane['streams'][k])
         if world > 1:

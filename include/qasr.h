@@ -157,6 +157,14 @@ void qasr_engine_destroy(qasr_engine* e);
  * T' = qasr_engine_out_frames(e, T). */
 int qasr_engine_forward(qasr_engine* e, void* stream, const float* feats, const int32_t* lens, int B, int T,
                         float* logp, int32_t* tokens, int32_t* lens_out);
+/* The same with the mel front-end in front (qasr_frontend_mel_planned into the caller's `feats` [B][n_mels][T_pad] /
+ * `feat_lens` [B] buffers, T_pad = qasr_frontend_frames(S, pad_to)): AudioToMelSpectrogramPreprocessor + encoder +
+ * decoder of EncDecCTCModel.forward (ctc_models.py:383-406) as ONE call - and, with graph replay on, one hipGraph launch
+ * per batch.  `frontend_plan`: a workspace filled by qasr_frontend_plan for this filterbank. */
+int qasr_engine_forward_audio(qasr_engine* e, void* stream, const float* audio, const int32_t* audio_lens, int B, int S,
+                              const float* fb, const float* window, int n_mels, float preemph, int pad_to,
+                              const void* frontend_plan, size_t plan_bytes, float* feats, int32_t* feat_lens, float* logp,
+                              int32_t* tokens, int32_t* lens_out);
 int qasr_engine_out_frames(const qasr_engine* e, int T);
 int qasr_engine_num_ops(const qasr_engine* e);
 

@@ -111,7 +111,7 @@ struct qasr_engine {
   // with one call; key = the caller's pointers, which a serving loop keeps stable
   bool use_graph = false;
   hipGraphExec_t gexec = nullptr;
-  const void* gkey[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  const void* gkey[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int gcalls = 0;                      // forwards seen with the current key (1st: direct launches, 2nd: capture)
 };
 
@@ -732,10 +732,22 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
   return QASR_OK;
 }
 
-int qasr_engine_forward(qasr_engine* e, void* stream, const float* feats, const int32_t* lens, int B, int T,
+// front-end of a forward_audio call (nullptr: the caller's features are the input)
+struct FrontArgs {
+  const float* audio;
+  const int32_t* audio_lens;
+  int S;
+  const float* fb;
+  const float* window;
+  int n_mels;
+  float preemph;
+  int pad_to;
+  const void* plan;
+  size_t plan_bytes;
+};
+
+static int forward_impl(qasr_engine* e, hipStream_t s, const FrontArgs* fe, float* feats, int32_t* lens, int B, int T,
                         float* logp, int32_t* tokens, int32_t* lens_out) {
-  if (!e || !feats || !lens || B <= 0 || T <= 0) return fail(QASR_ERR_ARG, "bad forward arguments");
-  hipStream_t s = (hipStream_t)stream;
   if (B != e->B || T != e->T0) {
     int rc = build_plan(e, B, T);
     if (rc) return rc;
@@ -748,6 +760,11 @@ int qasr_engine_forward(qasr_engine* e, void* stream, const float* feats, const 
   e->cur_lens = lens;
   e->stem = e->fuse_stem && stem_shape(e);
   auto enqueue = [&]() -> int {
+    if (fe) {                                                // mel front-end into the caller's feature / length buffers
+      int rc = qasr_frontend_mel_planned(s, fe->audio, fe->audio_lens, B, fe->S, fe->fb, fe->window, fe->n_mels, fe->preemph,
+                                         fe->pad_to, feats, lens, fe->plan, fe->plan_bytes);
+      if (rc) return fail(rc, "forward_audio: front-end");
+    }
     const qasr_domain_desc* ddoms = (const qasr_domain_desc*)(e->dblob + h.domains_off);
     if (!e->stem) launch_lens(s, lens, e->lens_all, ddoms, (int)h.n_domains, B);   // (k_stem derives them itself)
     for (uint32_t oi = 0; oi < h.n_ops; ++oi) {
@@ -758,14 +775,15 @@ int qasr_engine_forward(qasr_engine* e, void* stream, const float* feats, const 
     return QASR_OK;
   };
   if (e->use_graph && s != nullptr && !e->timing && !e->debug) {   // the legacy default stream cannot be captured
-    const void* key[5] = {feats, lens, logp, tokens, lens_out};
+    const void* key[8] = {feats, lens, logp, tokens, lens_out, fe ? fe->audio : nullptr, fe ? fe->audio_lens : nullptr,
+                          fe ? fe->plan : nullptr};
     bool same = true;
-    for (int i = 0; i < 5; ++i) same = same && key[i] == e->gkey[i];
+    for (int i = 0; i < 8; ++i) same = same && key[i] == e->gkey[i];
     if (!same) {                                             // new buffer set: drop the old graph, start over
       if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
       e->gexec = nullptr;
       e->gcalls = 0;
-      for (int i = 0; i < 5; ++i) e->gkey[i] = key[i];
+      for (int i = 0; i < 8; ++i) e->gkey[i] = key[i];
     }
     if (e->gexec) {
       HIPCHK(hipGraphLaunch(e->gexec, s));
@@ -795,6 +813,22 @@ int qasr_engine_forward(qasr_engine* e, void* stream, const float* feats, const 
   }
   HIPCHK(hipGetLastError());
   return QASR_OK;
+}
+
+int qasr_engine_forward(qasr_engine* e, void* stream, const float* feats, const int32_t* lens, int B, int T,
+                        float* logp, int32_t* tokens, int32_t* lens_out) {
+  if (!e || !feats || !lens || B <= 0 || T <= 0) return fail(QASR_ERR_ARG, "bad forward arguments");
+  return forward_impl(e, (hipStream_t)stream, nullptr, (float*)feats, (int32_t*)lens, B, T, logp, tokens, lens_out);
+}
+
+int qasr_engine_forward_audio(qasr_engine* e, void* stream, const float* audio, const int32_t* audio_lens, int B, int S,
+                              const float* fb, const float* window, int n_mels, float preemph, int pad_to,
+                              const void* frontend_plan, size_t plan_bytes, float* feats, int32_t* feat_lens, float* logp,
+                              int32_t* tokens, int32_t* lens_out) {
+  if (!e || !audio || !audio_lens || !fb || !window || !frontend_plan || !feats || !feat_lens || B <= 0 || S <= 0)
+    return fail(QASR_ERR_ARG, "bad forward_audio arguments");
+  FrontArgs fe{audio, audio_lens, S, fb, window, n_mels, preemph, pad_to, frontend_plan, plan_bytes};
+  return forward_impl(e, (hipStream_t)stream, &fe, feats, feat_lens, B, qasr_frontend_frames(S, pad_to), logp, tokens, lens_out);
 }
 
 // Replays every op `reps` times back to back between ONE pair of HIP events on `stream` and returns the

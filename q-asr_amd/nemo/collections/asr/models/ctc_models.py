@@ -245,6 +245,17 @@ class EncDecCTCModel(nn.Module):
                 and float(f.log_zero_guard_value) == 2.0 ** -24 and float(f.mag_power) == 2.0 and f.preemph is not None
                 and f.pad_value == 0 and isinstance(f.pad_to, int) and f.pad_to >= 0)
 
+    def _frontend_plan_for(self, device):
+        """(filterbank on `device`, qasr_frontend_plan workspace): the filterbank-only tables, built once per model / device."""
+        from qasr import engine as qengine
+        f = self.preprocessor.featurizer
+        fb = f.fb[0].to(device=device, dtype=torch.float32).contiguous()
+        key = (fb.data_ptr(), f.fb._version, str(device))
+        if getattr(self, '_frontend_plan_key', None) != key:
+            self._frontend_plan = qengine.frontend_plan(fb)
+            self._frontend_plan_key = key
+        return self._frontend_plan._qasr_fb, self._frontend_plan
+
     def _frontend_hip(self, signal, length):
         from qasr import engine as qengine
         f = self.preprocessor.featurizer
@@ -252,13 +263,9 @@ class EncDecCTCModel(nn.Module):
             return self.preprocessor(input_signal=signal, length=length)
         if f.dither > 0:
             signal = signal + f.dither * torch.randn_like(signal)
-        fb = f.fb[0].to(device=signal.device, dtype=torch.float32).contiguous()
-        key = (fb.data_ptr(), f.fb._version, str(signal.device))
-        if getattr(self, '_frontend_plan_key', None) != key:   # filterbank-only tables: built once per model / device
-            self._frontend_plan = qengine.frontend_plan(fb)
-            self._frontend_plan_key = key
-        return qengine.frontend_mel(signal.float().contiguous(), length, self._frontend_plan._qasr_fb, f.window.contiguous(),
-                                    float(f.preemph), int(f.pad_to), plan=self._frontend_plan)
+        fb, plan = self._frontend_plan_for(signal.device)
+        return qengine.frontend_mel(signal.float().contiguous(), length, fb, f.window.contiguous(), float(f.preemph),
+                                    int(f.pad_to), plan=plan)
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_signal=None, input_signal_length=None, processed_signal=None,
@@ -274,6 +281,18 @@ class EncDecCTCModel(nn.Module):
                 raise RuntimeError('the calibrated integer model runs on the MI355X HIP engine only: move the inputs '
                                    'to cuda (there is no CPU fallback for the quantised inference path)')
             eng = self._get_engine(ref.device)
+            f = self.preprocessor.featurizer
+            if has_in and self._frontend_hip_supported() and f.pad_to > 0:
+                # audio -> tokens as one engine call (qasr_engine_forward_audio): front-end, encoder and decoder replay as
+                # one hipGraph launch when the caller keeps its buffers
+                sig = input_signal.float().contiguous()
+                if f.dither > 0:
+                    sig = sig + f.dither * torch.randn_like(sig)
+                fb, plan = self._frontend_plan_for(ref.device)
+                log_probs, tokens, enc_len = eng.forward_audio(
+                    sig, input_signal_length.to(device=ref.device, dtype=torch.int32).contiguous(), fb,
+                    f.window.to(device=ref.device, dtype=torch.float32).contiguous(), plan, float(f.preemph), int(f.pad_to))
+                return log_probs, enc_len.long(), tokens.long()
             if has_in:
                 processed_signal, processed_signal_length = self._frontend_hip(input_signal, input_signal_length)
             log_probs, tokens, enc_len = eng.forward(processed_signal.float(), processed_signal_length)

@@ -9,7 +9,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('QASR_LIB', os.path.join(HERE, 'libqasr_hip.so'))   # QASR_LIB: A/B builds in one run
 
-SYMBOLS = ['qasr_engine_create', 'qasr_engine_destroy', 'qasr_engine_forward', 'qasr_engine_out_frames',
+SYMBOLS = ['qasr_engine_create', 'qasr_engine_destroy', 'qasr_engine_forward', 'qasr_engine_forward_audio', 'qasr_engine_out_frames',
            'qasr_engine_num_ops', 'qasr_engine_read_acc', 'qasr_engine_read_tensor', 'qasr_engine_last_op_ms',
            'qasr_engine_time_ops', 'qasr_engine_run_op', 'qasr_engine_op_label',
            'qasr_frontend_mel', 'qasr_frontend_plan', 'qasr_frontend_mel_planned', 'qasr_frontend_frames',
@@ -64,6 +64,7 @@ def load_library():
     lib.qasr_engine_time_ops.argtypes = [vp, vp, i32, vp, i32]
     lib.qasr_engine_run_op.argtypes = [vp, vp, i32]
     lib.qasr_engine_op_label.argtypes = [vp, i32, C.c_char_p, sz]
+    lib.qasr_engine_forward_audio.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, i32, C.c_float, i32, vp, sz, vp, vp, vp, vp, vp]
     lib.qasr_frontend_mel.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, C.c_float, i32, vp, vp, vp, sz]
     lib.qasr_frontend_mel_planned.argtypes = lib.qasr_frontend_mel.argtypes
     lib.qasr_frontend_plan.argtypes = [vp, vp, i32, vp, sz]
@@ -157,6 +158,36 @@ class Engine:
                                             _ptr(logp), _ptr(tokens), _ptr(enc_len)), 'qasr_engine_forward')
         self.B, self.T = B, T
         self._keep = (feats, lens32)        # keep inputs alive until the stream has consumed them
+        return logp, tokens, enc_len
+
+    def forward_audio(self, audio, audio_lens, fb, window, plan, preemph=0.97, pad_to=16, want_logp=True, stream=None,
+                      feats=None, feat_lens=None, out=None):
+        """qasr_engine_forward_audio: audio f32 [B, S] (cuda) -> (log_probs, tokens, enc_len) with the mel front-end inside the
+        engine's call (one hipGraph launch per batch once the buffer set has been seen twice).  `plan` = frontend_plan(fb);
+        `feats` / `feat_lens` / `out` = caller-owned buffers (stable pointers keep the captured graph)."""
+        assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 2 and audio.is_contiguous()
+        assert audio_lens.is_cuda and audio_lens.dtype == torch.int32 and fb.is_cuda and window.is_cuda
+        B, S = audio.shape
+        n_mels = fb.shape[0]
+        T = self.lib.qasr_frontend_frames(S, pad_to)
+        dev = audio.device
+        if feats is None:
+            feats = torch.empty(B, n_mels, T, device=dev, dtype=torch.float32)
+        if feat_lens is None:
+            feat_lens = torch.empty(B, device=dev, dtype=torch.int32)
+        To = self.out_frames(T)
+        if out is not None:
+            logp, tokens, enc_len = out
+        else:
+            logp = torch.empty(B, To, self.n_classes, device=dev, dtype=torch.float32) if want_logp else None
+            tokens = torch.empty(B, To, device=dev, dtype=torch.int32)
+            enc_len = torch.empty(B, device=dev, dtype=torch.int32)
+        _check(self.lib.qasr_engine_forward_audio(self._h, _stream_ptr(stream), _ptr(audio), _ptr(audio_lens), B, S, _ptr(fb),
+                                                  _ptr(window), n_mels, C.c_float(preemph), pad_to, _ptr(plan), plan.numel(),
+                                                  _ptr(feats), _ptr(feat_lens), _ptr(logp), _ptr(tokens), _ptr(enc_len)),
+               'qasr_engine_forward_audio')
+        self.B, self.T = B, T
+        self._keep = (audio, audio_lens, feats, feat_lens, fb, window, plan)
         return logp, tokens, enc_len
 
     # ---- parity hooks (debug engines)

@@ -164,3 +164,41 @@ def test_cli_inference_dynamic(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'WER:' in out.stdout
     assert 'path: dynamic device path (HIP)' in out.stdout
+
+
+def test_forward_audio_equals_frontend_plus_forward(golden_dir):
+    """qasr_engine_forward_audio (front-end inside the engine call, one hipGraph launch per batch) against
+    qasr_frontend_mel followed by qasr_engine_forward: identical features, log-probs, tokens and lengths - on the direct
+    launches of the first call, on the capture and on the replays."""
+    from qasr import engine, pack
+    d = np.load(os.path.join(golden_dir, 'net_quartznet_w8a8.npz'))
+    meta = json.loads(str(d['meta']))
+    cfg = topology.quartznet15x5()
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    blob, _ = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    from qasr import melbank
+    fb = torch.from_numpy(melbank.mel_filterbank(16000, 512, 64, 0.0, 8000.0).astype(np.float32)).cuda().contiguous()
+    win = torch.hann_window(320, periodic=False).cuda()
+    B, S = 4, 40000
+    audio = torch.from_numpy(synth.make_audio(B, S, seed=5)).cuda()
+    alen = torch.tensor([S, S - 7001, S - 16000, 9000], dtype=torch.int32).cuda()
+    e1, e2 = engine.Engine(blob, 0, graph=True), engine.Engine(blob, 0, graph=True)
+    feats, flen = engine.frontend_mel(audio, alen, fb, win, 0.97, 16)
+    lp0, tk0, el0 = e1.forward(feats, flen)
+    plan = engine.frontend_plan(fb)
+    st = torch.cuda.Stream()
+    fbuf = torch.empty_like(feats)
+    lbuf = torch.empty(B, dtype=torch.int32, device='cuda')
+    out = (torch.empty_like(lp0), torch.empty_like(tk0), torch.empty_like(el0))
+    torch.cuda.synchronize()
+    for call in range(4):                                      # direct, capture, replay, replay
+        for t in out:
+            t.zero_()
+        fbuf.zero_()
+        with torch.cuda.stream(st):
+            lp, tk, el = e2.forward_audio(audio, alen, fb, win, plan, 0.97, 16, feats=fbuf, feat_lens=lbuf, out=out)
+        torch.cuda.synchronize()
+        assert torch.equal(fbuf, feats) and torch.equal(lbuf, flen), call
+        assert torch.equal(lp, lp0) and torch.equal(tk, tk0) and torch.equal(el, el0), call
+    e1.close()
+    e2.close()
