@@ -218,9 +218,8 @@ def test_fused_stem_and_decoder_match_unfused(eng, golden_dir):
     cfg = topology.quartznet15x5()
     sd = synth.make_state_dict(cfg, meta['seed'])
     blob, _ = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
-    B, T = 32, 500
-    x = torch.from_numpy(synth.make_features(B, 64, T, 13)).cuda()
-    lens = torch.tensor([T - 13 * (i % 11) for i in range(B)])
+    cases = [(32, 500, [500 - 13 * (i % 11) for i in range(32)]),       # bench size, ragged
+             (3, 501, [501, 2, 77]), (2, 33, [33, 1]), (1, 129, [100])]    # odd frame counts, 1- and 2-frame utterances
     outs = []
     for stem, dec in ((1, 1), (0, 0)):
         os.environ['QASR_NO_FUSE_STEM'], os.environ['QASR_NO_FUSE_DEC'] = str(1 - stem), str(1 - dec)
@@ -228,15 +227,20 @@ def test_fused_stem_and_decoder_match_unfused(eng, golden_dir):
             e = eng.Engine(blob, 0)
         finally:
             del os.environ['QASR_NO_FUSE_STEM'], os.environ['QASR_NO_FUSE_DEC']
-        lp, tk, el = e.forward(x, lens)
-        labels = e.op_labels()
-        assert ('k_stem' in labels) == bool(stem) and ('k_dec' in labels) == bool(dec), labels[:4] + labels[-3:]
-        assert ('k_quant_in' in labels) != bool(stem) and ('k_logsoftmax' in labels) != bool(dec)
-        outs.append((lp.cpu().numpy(), tk.cpu().numpy(), el.cpu().numpy()))
+        res = []
+        for B, T, ls in cases:
+            x = torch.from_numpy(synth.make_features(B, 64, T, 13 + T)).cuda()
+            lp, tk, el = e.forward(x, torch.tensor(ls))
+            labels = e.op_labels()
+            assert ('k_stem' in labels) == bool(stem) and ('k_dec' in labels) == bool(dec), labels[:4] + labels[-3:]
+            assert ('k_quant_in' in labels) != bool(stem) and ('k_logsoftmax' in labels) != bool(dec)
+            res.append((lp.cpu().numpy(), tk.cpu().numpy(), el.cpu().numpy()))
+        outs.append(res)
         e.close()
-    for a, b in zip(outs[0], outs[1]):
-        assert np.array_equal(a, b)
-    assert np.array_equal(outs[0][2], (lens.numpy() + 1) // 2)
+    for (B, T, ls), ra, rb in zip(cases, outs[0], outs[1]):
+        for a, b in zip(ra, rb):
+            assert np.array_equal(a, b), (B, T)
+        assert np.array_equal(ra[2], (np.array(ls) + 1) // 2)
 
 
 def test_steps_in_flight_match_serial(eng, golden_dir):
