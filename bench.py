@@ -432,12 +432,20 @@ def run(args):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()                                             # (default stream, idle: the region's device-side origin)
         t0 = time.perf_counter()
         last = {}
         for i in range(steps):
             last[i % S] = step(lane, i, gathered)
         t_enq = time.perf_counter() - t0
+        ends = []
+        for st in lane['streams']:                               # when each stream's last step finished (diagnostic)
+            e_ = torch.cuda.Event(enable_timing=True)
+            e_.record(st)
+            ends.append(e_)
         torch.cuda.synchronize()
+        log('streams finished at ' + ', '.join(f'{ev0.elapsed_time(e_):.2f}' for e_ in ends) + ' ms after the region began')
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0

@@ -23,10 +23,11 @@ extern template int launch_sep2_inst<128, true>(hipStream_t, const SepP&);
 bool sep2_takes(const SepP& p) { return p.gen == 2 && sep2_shape_ok(p); }
 // frames per work-group of a k_sep2 launch: 128 for the depthwise-separable layers when the engine asks for it
 // (throughput mode: every weight fragment then feeds four frame tiles, B * Tp / 128 work-groups per launch), else the
-// engine's 32 / 64; the residual layers stay on 64 (0.454 vs 0.462 ms per step with them on 128: twice the work-group
-// time on half the CUs is no gain there) unless QASR_RES_TILE128=1 (A/B runs)
+// engine's 32 / 64.  The block-end (residual) layers too: with the decoder and the stem fused it is 0.417 vs 0.424 ms per step
+// and steadier (four 64-work-group launches fit the chip side by side, four 128-work-group ones queue); QASR_RES_TILE128=0
+// keeps them on 64 (A/B runs)
 static int sep2_tile(const SepP& p) {
-  static const bool res128 = [] { const char* g = getenv("QASR_RES_TILE128"); return g && atoi(g) != 0; }();
+  static const bool res128 = [] { const char* g = getenv("QASR_RES_TILE128"); return !g || atoi(g) != 0; }();
   if (p.tile == 128)
     return (p.K > 0 && p.e.Tp % 128 == 0 && (res128 || !(p.e.flags & QASR_F_RESADD))) ? 128 : 64;
   return p.tile == 64 ? 64 : 32;
