@@ -228,6 +228,12 @@ int qasr_pw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t
 int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, const int32_t* bias, int B, int c,
                      int kernel, int kpad, int stride, int dilation, int padding, int T, int Tp, int T_out, int Tp_out,
                      int32_t* acc);
+/* dense (groups = 1) int_conv accumulator for any kernel / stride / dilation (Jasper's convs; quant_modules.py:301-305):
+ * w s8 [cout_pad128][kernel][cin_pad128]; bias i32 [cout_pad128] or NULL (x_unsigned: + 128 * sum(W[co]) over all taps);
+ * acc i32 [B][cout][Tp_out] */
+int qasr_dense_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, const int32_t* bias, int B, int cin,
+                        int cin_pad, int cout, int kernel, int stride, int dilation, int padding, int T, int Tp, int T_out,
+                        int Tp_out, int32_t* acc);
 /* fixedpoint_mul.forward for one operand (quant_utils.py:187-198,213): q = clamp(rint(acc*m[c]), lo, hi)
  * with m[c] = mantissa*2^-e as f64; exact_z selects the float32 round trip through sb[c]. */
 int qasr_requant(void* stream, const int32_t* acc, const double* m, const float* sb, int exact_z, int relu,

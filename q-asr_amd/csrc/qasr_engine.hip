@@ -1013,6 +1013,41 @@ int qasr_dw_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t
   return QASR_OK;
 }
 
+int qasr_dense_conv_acc(void* stream, const int8_t* x, int x_unsigned, const int8_t* w, const int32_t* bias, int B, int cin,
+                        int cin_pad, int cout, int kernel, int stride, int dilation, int padding, int T, int Tp, int T_out,
+                        int Tp_out, int32_t* acc) {
+  if (!x || !w || !acc || cin_pad % 128 || cin > cin_pad || Tp % 64 || Tp_out % 64 || T > Tp || T_out > Tp_out || kernel < 1 ||
+      stride < 1 || dilation < 1 || B < 1 || cout < 1)
+    return fail(QASR_ERR_ARG, "dense_conv_acc: bad arguments");
+  void* z;
+  int rc = zero_buf(&z);
+  if (rc) return rc;
+  if ((size_t)rup(cout, 128) * 8 > kZeroBytes) return fail(QASR_ERR_ARG, "cout too large");
+  DenseP p{};                          // the generic dense conv kernel (k_dense) with no consumers: accumulators only
+  p.x = x;
+  p.w = w;
+  p.bias = bias ? bias : (const int32_t*)z;
+  p.cin = cin;
+  p.cin_pad = cin_pad;
+  p.K = kernel;
+  p.stride = stride;
+  p.dilation = dilation;
+  p.padding = padding;
+  p.T_in = T;
+  p.Tp_in = Tp;
+  p.x_unsigned = x_unsigned;
+  p.e.sb = (const float*)z;
+  p.e.acc_dbg = acc;
+  p.e.T = T_out;
+  p.e.Tp = Tp_out;
+  p.e.cout = cout;
+  p.e.B = B;
+  p.e.lens = (const int32_t*)z;
+  launch_dense((hipStream_t)stream, p);
+  HIPCHK(hipGetLastError());
+  return QASR_OK;
+}
+
 int qasr_sep_layer(void* stream, const qasr_sep_layer_args* a, char* label, size_t label_cap) {
   if (!a || !a->x || !a->w || !a->bias || !a->lens || a->B < 1 || a->cin < 1 || a->cout < 1 || a->Tp % 64 || a->T > a->Tp ||
       a->n_outs < 0 || a->n_outs > QASR_MAX_OUTS || (a->tile != 32 && a->tile != 64 && a->tile != 128))

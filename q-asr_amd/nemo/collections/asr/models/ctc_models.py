@@ -174,8 +174,8 @@ class EncDecCTCModel(nn.Module):
         return all(mc.conv.fix_bn and mc.conv.quant_mode == 'symmetric' for mc in self._masked_convs())
 
     def _get_dynamic_runner(self, device):
-        """DynamicRunner for the live weights, or None when the topology is outside its scope (dense k>1 convs, several
-        residual panes): those models keep the host modules in dynamic mode."""
+        """DynamicRunner for the live weights (both model families), or None if it declines the topology: such a model
+        keeps the host modules in dynamic mode."""
         key = ('dyn', self._quant_version, device.index or 0)
         if self._engine_key != key:
             from qasr import dynamic, engine as qengine

@@ -14,8 +14,8 @@ A float tensor never exists between layers: it is carried as (integers, float32 
 `qasr_dyn_view` hands to the kernels.  No call synchronises with the host.  Weights are static and prepared once
 (BN fold, per-channel weight integers in the kernels' layouts).
 
-Scope: separable blocks and 1x1 convs with at most one residual pane per block (the QuartzNet family, BASELINE.json
-config 1); Jasper's dense k>1 convs in dynamic mode stay on the host façade.
+Scope: both model families - separable blocks (QuartzNet) and dense k>1 / strided convs with dense residual panes
+(Jasper; accumulators from the generic dense kernel behind qasr_dense_conv_acc).
 """
 import ctypes as C
 
@@ -60,14 +60,21 @@ class _Conv:
         self.s_w = s_w.float().to(dev).contiguous()
         self.bprime = None if b is None else b.float().to(dev).contiguous()
         self.wsum128 = (128 * wi.reshape(self.cout, -1).sum(1)).to(torch.int32).to(dev).contiguous()
+        self.dense = False
         if site is not None and site.role == 'dw':
             K = w.shape[2]
             self.kpad = _rup(K, 4)
             wp = torch.zeros(self.cout, self.kpad, dtype=torch.int8)
             wp[:, :K] = wi[:, 0].to(torch.int8)
             self.w = wp.to(dev)
+        elif w.shape[2] > 1 or (site is not None and site.stride > 1):
+            self.dense = True                                 # [cout_pad][K][cin_pad], the generic dense kernel's layout
+            cin, K = w.shape[1], w.shape[2]
+            self.cin_pad = _rup(cin, 128)
+            wp = torch.zeros(self.cout_pad, K, self.cin_pad, dtype=torch.int8)
+            wp[:self.cout, :, :cin] = wi.permute(0, 2, 1).to(torch.int8)
+            self.w = wp.to(dev)
         else:
-            assert w.shape[2] == 1, 'dynamic device path: dense k>1 convs are not covered (see module docstring)'
             cin = w.shape[1]
             self.cin_pad = _rup(cin, 128)
             wp = np.zeros((self.cout_pad, self.cin_pad), np.int8)
@@ -86,11 +93,7 @@ class DynamicRunner:
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if torch.is_tensor(v)}
         self.convs = {}
         for sites in self.plan:
-            if sum(s.role == 'res' for s in sites) > 1:
-                raise NotImplementedError('dynamic device path: one residual pane per block (QuartzNet family)')
             for s in sites:
-                if s.role == 'dense' and s.kernel > 1:
-                    raise NotImplementedError('dynamic device path: dense k>1 convs are not covered')
                 w = sd[f'{s.key}.conv.weight'] if f'{s.key}.conv.weight' in sd else sd[f'{s.key}.weight']
                 b = sd.get(f'{s.key}.conv.bias', sd.get(f'{s.key}.bias'))
                 if s.bn_key is not None:
@@ -151,7 +154,11 @@ class DynamicRunner:
         T_out = (T + 2 * padding - dilation * (kernel - 1) - 1) // stride + 1
         Tpo = _rup(T_out, 64)
         acc = torch.zeros(B, cv.cout, Tpo, dtype=torch.int32, device=self.dev)
-        if cv.site is not None and cv.site.role == 'dw':
+        if cv.dense:
+            _check(self.lib.qasr_dense_conv_acc(_stream_ptr(), _ptr(codes), int(unsigned), _ptr(cv.w), _ptr(bias), B, codes.shape[1],
+                                                cv.cin_pad, cv.cout, kernel, stride, dilation, padding, T, Tp, T_out, Tpo,
+                                                _ptr(acc)), 'qasr_dense_conv_acc')
+        elif cv.site is not None and cv.site.role == 'dw':
             _check(self.lib.qasr_dw_conv_acc(_stream_ptr(), _ptr(codes), int(unsigned), _ptr(cv.w), _ptr(bias), B, cv.cout,
                                              kernel, cv.kpad, stride, dilation, padding, T, Tp, T_out, Tpo, _ptr(acc)),
                    'qasr_dw_conv_acc')
@@ -178,21 +185,24 @@ class DynamicRunner:
         feats = feats.to(self.dev, torch.float32).contiguous()
         lens = lens.to(self.dev, torch.int32).contiguous()
         B, _, T = feats.shape
-        cur = _Value(None, None, feats.shape[1], T, False, feats=feats)
+        xs = [_Value(None, None, feats.shape[1], T, False, feats=feats)]   # block inputs (dense residual keeps them all)
         for bi, sites in enumerate(self.plan):
-            block_in, lens_in = cur, lens
-            v, cl = cur, lens
+            lens_in = lens
+            v, cl = xs[-1], lens
             for s in (s for s in sites if s.role != 'res'):
                 v, cl = self._masked_conv(s, v, cl, B)
                 v.relu = s.relu_after
             rs = [s for s in sites if s.role == 'res']
-            if rs:
-                r, _ = self._masked_conv(rs[0], block_in, lens_in, B)
-                # res_act(out, out_sf, res_out, res_sf) (jasper.py:680-682): QuantAct on identity + x, no mask
+            for s in rs:
+                r, _ = self._masked_conv(s, xs[s.pane], lens_in, B)
+                # res_act(out, out_sf, res_out, res_sf) (jasper.py:664-682): a dynamic QuantAct on identity + x after
+                # EVERY pane, no mask; from the second pane on x is the previous res_act's codes on its per-tensor scale
                 codes, S = self._quant_act(v, self.abit, False, cl, B, ident=r, mask=False)
                 v = _Value(codes, S, v.C, v.T, False)
             v.relu = True                                     # self.mout (jasper.py:687)
-            cur, lens = v, cl
+            xs = xs + [v] if (rs and self.cfg.blocks[bi].residual_dense) else [v]
+            lens = cl
+        cur = xs[-1]
         # decoder (conv_asr.py:270-275): QuantAct (signed) -> 1x1 conv with bias -> log_softmax
         codes, S = self._quant_act(cur, self.abit, False, lens, B, mask=False)
         out = self._conv(self.dec, codes, S, False, B, cur.T)

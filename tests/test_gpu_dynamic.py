@@ -29,7 +29,11 @@ def _load(golden_dir, name):
 
 
 def _cfg(name):
-    return topology.mini_quartznet() if 'miniq' in name else topology.quartznet15x5()
+    if 'miniq' in name:
+        return topology.mini_quartznet()
+    if 'minij' in name:
+        return topology.mini_jasper()
+    return topology.quartznet15x5() if 'quartznet' in name else topology.jasper10x5dr()
 
 
 def _run(golden_dir, name):
@@ -48,7 +52,7 @@ def _codes(t):
     return (c.view(torch.uint8) if t['unsigned'] else c).cpu().numpy().astype(np.int64)
 
 
-@pytest.mark.parametrize('name', ['net_miniq_dyn_w8a8', 'net_miniq_dyn_w6a6'])
+@pytest.mark.parametrize('name', ['net_miniq_dyn_w8a8', 'net_miniq_dyn_w6a6', 'net_minij_dyn_w8a8'])
 def test_dynamic_mini_net_every_accumulator(golden_dir, name):
     """Every conv's input codes and int32 accumulator equal the reference's rint(x_int) / rint(conv_int) in dynamic
     mode (ragged lengths: the mask is part of what each QuantAct ranges over), then lengths, tokens and logits."""
@@ -63,9 +67,11 @@ def test_dynamic_mini_net_every_accumulator(golden_dir, name):
     np.testing.assert_allclose(out['log_probs'].cpu().numpy(), d['log_probs'], rtol=1e-4, atol=1e-5)
 
 
-def test_dynamic_quartznet_checksums(golden_dir):
-    """All 171 convs of QuartzNet15x5 in dynamic mode: checksums of accumulators and input codes, tokens."""
-    d, meta, r, out = _run(golden_dir, 'net_quartznet_dyn_w8a8')
+@pytest.mark.parametrize('name', ['net_quartznet_dyn_w8a8', 'net_jasper_dyn_w8a8'])
+def test_dynamic_full_net_checksums(golden_dir, name):
+    """All 171 convs of QuartzNet15x5 / all 109 of Jasper10x5dr (dense k>1 and strided convs, up to ten sequentially
+    re-ranged residual panes per block) in dynamic mode: checksums of accumulators and input codes, tokens."""
+    d, meta, r, out = _run(golden_dir, name)
     assert len(r.trace) == meta['nconv']
     for i, t in enumerate(r.trace):
         got = np.concatenate([O.checksum(t['acc'].cpu().numpy()), O.checksum(_codes(t))])

@@ -9,8 +9,8 @@ import pytest
 from oracle import int_oracle as O
 from qasr import synth, topology
 
-NETS = ['net_miniq_w8a8', 'net_miniq_w8a8_pct', 'net_miniq_w6a6', 'net_minij_w8a8', 'net_miniq_dyn_w8a8', 'net_miniq_dyn_w6a6']
-FULL = ['net_quartznet_w8a8', 'net_quartznet_w6a6', 'net_jasper_w8a8', 'net_quartznet_dyn_w8a8']
+NETS = ['net_miniq_w8a8', 'net_miniq_w8a8_pct', 'net_miniq_w6a6', 'net_minij_w8a8', 'net_miniq_dyn_w8a8', 'net_miniq_dyn_w6a6', 'net_minij_dyn_w8a8']
+FULL = ['net_quartznet_w8a8', 'net_quartznet_w6a6', 'net_jasper_w8a8', 'net_quartznet_dyn_w8a8', 'net_jasper_dyn_w8a8']
 
 
 def load(golden_dir, name):
