@@ -243,6 +243,34 @@ def test_fused_stem_and_decoder_match_unfused(eng, golden_dir):
         assert np.array_equal(ra[2], (np.array(ls) + 1) // 2)
 
 
+def test_long_utterances_tile_sizes_agree(eng, golden_dir):
+    """30-second utterances (2999 mel frames -> 1500 encoder frames: 47 / 24 / 12 time tiles per utterance, the last
+    one partial) with ragged lengths: the three tile sizes and both kernel generations produce identical log-probs,
+    tokens and lengths, and re-running is bit-reproducible."""
+    d, meta = _load(golden_dir, 'net_quartznet_w8a8')
+    cfg = topology.quartznet15x5()
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    blob, _ = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    B, T = 3, 2999
+    x = torch.from_numpy(synth.make_features(B, 64, T, 17)).cuda()
+    lens = torch.tensor([2999, 1777, 64])
+    ref = None
+    for fam in (dict(gen=2), dict(gen=2, wide_tiles=True, tile128=0), dict(gen=2, wide_tiles=True, tile128=1), dict(gen=1)):
+        fam = dict(fam)
+        e = _engine_gen(eng, blob, fam.pop('gen'), **fam)
+        lp, tk, el = e.forward(x, lens)
+        lp2, tk2, _ = e.forward(x, lens)
+        out = (lp.cpu().numpy(), tk.cpu().numpy(), el.cpu().numpy())
+        assert np.array_equal(out[1], tk2.cpu().numpy()) and np.array_equal(out[0], lp2.cpu().numpy())
+        e.close()
+        assert np.array_equal(out[2], (lens.numpy() + 1) // 2)
+        if ref is None:
+            ref = out
+        else:
+            for a, b_ in zip(ref, out):
+                assert np.array_equal(a, b_), fam
+
+
 def test_steps_in_flight_match_serial(eng, golden_dir):
     """bench.py keeps several steps in flight (one engine + HIP stream each): kernels of different steps interleave on
     the CUs, which exposes any tensor whose arena slot is recycled before its last reader (the halo reads of a fused
