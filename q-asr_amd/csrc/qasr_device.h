@@ -17,58 +17,21 @@ __device__ __forceinline__ int requant_clamp(int z, double M, int lo, int hi) {
   t = fmin(fmax(t, MAGIC_RNE + (double)lo), MAGIC_RNE + (double)hi);
   return __double2loint(t);
 }
-// Same result, cheaper on average: fp64 VALU ops issue at ~1/4 rate on gfx950, so the product is first formed in
-// float32 and the fp64 path above only runs when that cannot decide the rounding.
-//   p = fl32(z) * fl32(M):  |p - z*M| <= |z*M| * (2^-23 + 2^-48)  (|z| < 2^24 exact in f32; two roundings of 2^-24 each;
-//   a batch holding |z| >= 2^24, where the conversion itself rounds, takes the fp64 path).
-//   Inside the target range (|p| <= R = max(|lo|,|hi|) + 1) the error is < R * 1.2e-7, hence r = rint(p) is the exact
-//   answer unless p lies within tau = R * 1.5e-7 of a half-integer (p - r is exact in f32); outside the range both the
-//   exact and the approximate product round beyond lo / hi and the clamp (applied to r, in float) gives the same result.
-//   Batches holding an ambiguous value (~4 % of the 1024-value wave batches for 8-bit ranges) take the fp64 path.
-// The wave votes once for a whole batch of values, so the fallback costs one uniform branch.
-__device__ __forceinline__ float requant_tau(float lo, float hi) { return (fmaxf(fabsf(lo), fabsf(hi)) + 1.0f) * 1.5e-7f; }
-__device__ __forceinline__ bool requant_ambiguous(float p, float r, float tau) { return 0.5f - fabsf(p - r) <= tau; }
-
-// requantise N accumulators of one lane (same multiplier): fast float32 path with exact fp64 fallback
+// Batches of values sharing a multiplier (k_sep / k_utt / k_requant epilogues).  Round 1 formed the product in float32
+// first and took the fp64 path only for a batch holding a value within tau of a rounding tie (54 cycles per value with
+// the wave vote); the round-2 micro-benchmarks (profiles/microbench/ubench.hip) put fp64 fma at the integer ALU's issue
+// rate on gfx950, which makes the exact form the cheap one (~20 cycles per value) - so that is all there is now.
 template <int N>
 __device__ __forceinline__ void requant_batch(int (&q)[N], const int (&z)[N], double M, int lo, int hi) {
-  const float Mf = (float)M, flo = (float)lo, fhi = (float)hi, tau = requant_tau(flo, fhi);
-  bool amb = false;
-  float r[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const float p = __fmul_rn((float)z[i], Mf);
-    r[i] = rintf(p);
-    amb |= requant_ambiguous(p, r[i], tau) | (__builtin_abs(z[i]) >= (1 << 24));   // (float)z inexact: a third rounding
-  }
-  if (__builtin_expect(__any(amb), 0)) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) q[i] = requant_clamp(z[i], M, lo, hi);
-  } else {
-#pragma unroll
-    for (int i = 0; i < N; ++i) q[i] = (int)__builtin_amdgcn_fmed3f(r[i], flo, fhi);
-  }
+  for (int i = 0; i < N; ++i) q[i] = requant_clamp(z[i], M, lo, hi);
 }
 
 // same with one multiplier per group of 4 consecutive values (4 channels x 4 values in the whole-utterance kernel)
 template <int N>
 __device__ __forceinline__ void requant_batch4(int (&q)[N], const int (&z)[N], const double (&M)[N / 4], int lo, int hi) {
-  const float flo = (float)lo, fhi = (float)hi, tau = requant_tau(flo, fhi);
-  bool amb = false;
-  float r[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const float p = __fmul_rn((float)z[i], (float)M[i / 4]);
-    r[i] = rintf(p);
-    amb |= requant_ambiguous(p, r[i], tau) | (__builtin_abs(z[i]) >= (1 << 24));
-  }
-  if (__builtin_expect(__any(amb), 0)) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) q[i] = requant_clamp(z[i], M[i / 4], lo, hi);
-  } else {
-#pragma unroll
-    for (int i = 0; i < N; ++i) q[i] = (int)__builtin_amdgcn_fmed3f(r[i], flo, fhi);
-  }
+  for (int i = 0; i < N; ++i) q[i] = requant_clamp(z[i], M[i / 4], lo, hi);
 }
 
 // rint(z*M) as a double (RESADD sums two of these before clamping, quant_utils.py:211)
