@@ -346,3 +346,36 @@ def test_w6_blob_is_sub_byte_packed(golden_dir):
         packed = [bool(o['flags'] & F_W6PACK) for o in p.final_ops if o['kind'] in (1, 2, 3)]
         assert all(packed) if meta['wbit'] <= 6 else not any(packed)
     assert sizes['net_quartznet_w6a6'] <= 0.78 * sizes['net_quartznet_w8a8'], sizes
+
+
+def test_dynamic_runner_static_halves_on_cpu():
+    """qasr.dynamic._Conv (the static half of a QuantConv1d in the dynamic device path): weight integers in the three kernel
+    layouts (depthwise [C][kpad4], 1x1 fragment order, dense [cout_pad][K][cin_pad]), weight scales, 128 * sum(W)."""
+    import torch
+    from qasr import dynamic, quant_math as Q
+    from qasr.pack import fragment_order
+    from qasr.topology import ConvSite
+    g = torch.Generator().manual_seed(0)
+    # depthwise k = 11
+    w = torch.randn(24, 1, 11, generator=g)
+    s = ConvSite('x.0', None, 0, 'dw', 24, 24, 11, 1, 1, 5, 24, True, False)
+    c = dynamic._Conv(s, w, None, 8, 'cpu')
+    wi, sw = Q.weight_integers(w, 8)
+    assert c.kpad == 12 and c.w.shape == (24, 12) and not c.dense
+    assert torch.equal(c.w[:, :11].long(), wi[:, 0].long()) and int(c.w[:, 11].abs().sum()) == 0
+    assert torch.equal(c.s_w, sw) and torch.equal(c.wsum128.long(), 128 * wi.long().reshape(24, -1).sum(1))
+    # 1x1 40 -> 72 with bias
+    w = torch.randn(72, 40, 1, generator=g)
+    b = torch.randn(72, generator=g)
+    c = dynamic._Conv(ConvSite('x.1', None, 0, 'pw', 40, 72, 1, 1, 1, 0, 1, False, True), w, b, 8, 'cpu')
+    wi, _ = Q.weight_integers(w, 8)
+    ref = np.zeros((128, 128), np.int8)
+    ref[:72, :40] = wi[:, :, 0].numpy().astype(np.int8)
+    assert c.cout_pad == 128 and c.cin_pad == 128 and not c.dense
+    assert np.array_equal(c.w.numpy(), fragment_order(ref)) and torch.equal(c.bprime, b)
+    # dense k = 5, stride 2
+    w = torch.randn(32, 16, 5, generator=g)
+    c = dynamic._Conv(ConvSite('x.2', None, 0, 'dense', 16, 32, 5, 2, 1, 2, 1, False, True), w, None, 6, 'cpu')
+    wi, _ = Q.weight_integers(w, 6)
+    assert c.dense and c.w.shape == (128, 5, 128) and int(wi.abs().max()) <= 31
+    assert torch.equal(c.w[:32, :, :16].long(), wi.permute(0, 2, 1).long()) and int(c.w[32:].abs().sum()) == 0
