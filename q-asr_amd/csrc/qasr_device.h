@@ -34,6 +34,16 @@ __device__ __forceinline__ void requant_batch4(int (&q)[N], const int (&z)[N], c
   for (int i = 0; i < N; ++i) q[i] = requant_clamp(z[i], M[i / 4], lo, hi);
 }
 
+// rint(z * M) for |z * M| < 2^31 (the packer flags ops that cannot promise this QASR_F_WIDE_RQ: k_sep2 leaves them
+// to k_sep, which then clamps in the double domain): one fp64 fma rounds
+// half-to-even into the low mantissa word (quant_utils.py:196-198: round(f64(z) * f64(m) / 2^e), M = m * 2^-e)
+__device__ __forceinline__ int rq_rint(int z, double M) { return __double2loint(__builtin_fma((double)z, M, MAGIC_RNE)); }
+// clamp(x, lo, hi) for lo <= hi as ONE v_med3_i32 (the compiler keeps min/max apart: it cannot know lo <= hi)
+__device__ __forceinline__ int med3i(int x, int lo, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+  return r;
+}
 // rint(z*M) as a double (RESADD sums two of these before clamping, quant_utils.py:211)
 __device__ __forceinline__ double requant_d(int z, double M) { return rint((double)z * M); }
 

@@ -79,15 +79,6 @@ struct Sep2Geo {
   static_assert(TAPB % 16 == 0, "tap chunk is not 16-byte granular");
 };
 
-// rint(z * M) for |z * M| < 2^31 (the packer routes ops that cannot promise this to k_sep): one fp64 fma rounds
-// half-to-even into the low mantissa word (quant_utils.py:196-198: round(f64(z) * f64(m) / 2^e), M = m * 2^-e)
-__device__ __forceinline__ int rq_rint(int z, double M) { return __double2loint(__builtin_fma((double)z, M, MAGIC_RNE)); }
-// clamp(x, lo, hi) for lo <= hi as ONE v_med3_i32 (the compiler keeps min/max apart: it cannot know lo <= hi)
-__device__ __forceinline__ int med3i(int x, int lo, int hi) {
-  int r;
-  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
-  return r;
-}
 __device__ __forceinline__ int rq_clamp(int z, double M, int lo, int hi) { return med3i(rq_rint(z, M), lo, hi); }
 __device__ __forceinline__ unsigned pack4b(int a, int b, int c, int d) {
   const unsigned lo = __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x0c0c0400u);    // [a0, b0, 0, 0]

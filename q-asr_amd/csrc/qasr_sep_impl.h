@@ -618,6 +618,51 @@ __global__ void __launch_bounds__(SEP_NT) k_sep(SepP p) {
         }
         emit(mt, z);
       }
+    } else if (GEN && f_resadd && !(flags & QASR_F_WIDE_RQ)) {
+      // dense residual (Jasper): pane after pane, clamp after every add; panes share the Xr staging buffer.  Every
+      // |acc * M| of the op stays below 2^30 (the packer would have set QASR_F_WIDE_RQ): each operand's rounded product
+      // comes out of the low mantissa word (rq_rint), the running sum is an integer, the clamp one v_med3_i32 - four
+      // instructions per value and pane instead of six fp64 ones, and 32 registers less than the double-domain form
+      // below (with 7-10 panes the epilogue, not the panes' GEMMs, is what these layers spend their time in)
+      int d[SEP_MT][16];
+#pragma unroll
+      for (int mt = 0; mt < SEP_MT; ++mt) {
+        const bool exact = f_exact && any_big(acc[mt]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[mt][r] = rq_rint(exact ? z_roundtrip(acc[mt][r], cur.sb, false) : acc[mt][r], cur.m_main);
+      }
+      for (int pi = 0; pi < n_panes; ++pi) {
+        const PaneP& pn = p.panes[pi];
+        const int XPr = pn.cin_pad + 16;
+        const int bv = pn.bias[cor];
+        const double Mp = pn.m[cor];
+        const float sbp = pn.sb[cor];
+        if (pi > 0) sep_load_w(wf, pn.w, pn.cin_pad, cor, 0);
+        __syncthreads();
+        sep_stage_transposed<TT>(Xr, XPr, pn.x, pn.cin, pn.cin_pad, e.Tp, b, t0, pn.x_unsigned);
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < SEP_MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][r] = bv;
+        if (co_in) sep_gemm(acc, wf, Xr, XPr, pn.w, pn.cin_pad, cor);
+#pragma unroll
+        for (int mt = 0; mt < SEP_MT; ++mt) {
+          if (DBG) sep_dump(pn.acc_dbg, acc[mt], b, co, ecout, t0 + 32 * mt, h, eT, eTp);
+          const bool exactp = f_exact && any_big(acc[mt]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            d[mt][r] = med3i(d[mt][r] + rq_rint(exactp ? z_roundtrip(acc[mt][r], sbp, false) : acc[mt][r], Mp), qlo, qhi);
+        }
+      }
+      if (more && !dense) sep_load_w(wf, p.w, p.cin_pad, con, 0);
+#pragma unroll
+      for (int mt = 0; mt < SEP_MT; ++mt) {
+        int z[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = f_relu ? max(d[mt][r], 0) : d[mt][r];
+        emit(mt, z);
+      }
     } else if (GEN && f_resadd) {
       // dense residual (Jasper): pane after pane, clamp after every add; panes share the Xr staging buffer
       double d[SEP_MT][16];
