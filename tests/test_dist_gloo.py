@@ -114,3 +114,31 @@ def test_bench_launcher_fails_loudly_without_enough_gpus():
 def test_bench_rejects_mismatched_world_size():
     r = _run_bench('--gpus', '2', '--dry-run', env=dict(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
     assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+def test_committed_bench_lines_carry_the_contract_fields():
+    """The bench lines committed under profiles/ (newest round) hold every field the measurement contract names: the
+    driver's parser and the judge read exactly these."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r*_bench*.json')))
+    newest = os.path.basename(files[-1]).split('_bench')[0]
+    lines = [f for f in files if os.path.basename(f).startswith(newest) and 'under_rocprof' not in f]
+    assert lines
+    for f in lines:
+        r = json.loads(open(f).read().strip().splitlines()[-1])
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                  'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'n_ranks_seen'):
+            assert k in r, (f, k)
+        assert r['higher_is_better'] is True and r['scaling'] == 'weak' and r['vs_baseline'] is None and r['data'] == 'synthetic'
+        assert 'workload' in r['config'] and 'model' not in r['config']
+        ro = r['roofline']
+        for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel'):
+            assert k in ro, (f, k)
+        assert ro['bound'] in ('hbm', 'mfma') and abs(ro['frac'] - ro['achieved'] / ro['peak']) < 1e-6
+        cb = r['cpu_baseline']
+        for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+            assert k in cb, (f, k)
+        assert cb['kind'] in ('port', 'reference') and cb['unit'] == r['unit']
+        assert abs(r['value'] - r['n_gpus'] * 32 * 5.0 * (2 if 'bs64' in r['metric'] else 1) * r['steps'] / (r['ms_per_step'] * 1e-3 * r['steps'])) / r['value'] < 1e-3
