@@ -43,13 +43,24 @@ __global__ void __launch_bounds__(DEC_NT) k_dec(DecP p) {
   if (blockIdx.y == 0 && tid == 0 && p.lens_out) p.lens_out[b] = p.lens[b];
   // ---- the tile's codes: two 16-byte granules (16 frames each) per channel row; rows >= cin are zero
   const unsigned flip = p.x_unsigned ? 0x80808080u : 0u;                  // u8 codes are fed as x - 128 (bias carries 128 sum(W))
-  for (int g = tid; g < 2 * p.cin_pad; g += DEC_NT) {
-    const int c = g >> 1, half = g & 1;
-    v4i v = {0, 0, 0, 0};
-    if (c < p.cin) v = *(const v4i*)(p.x + ((size_t)b * p.cin + c) * p.Tp + t0 + 16 * half);
-    v[0] ^= flip, v[1] ^= flip, v[2] ^= flip, v[3] ^= flip;
-    if (c >= p.cin) v = (v4i){0, 0, 0, 0};
-    *(lds_v4i*)(Xd + c * 32 + 16 * half) = v;
+  for (int base = tid; base < 2 * p.cin_pad; base += 4 * DEC_NT) {        // four granules per thread in flight together
+    v4i r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = min(base + u * DEC_NT, 2 * p.cin_pad - 1), c = min(g >> 1, p.cin - 1), half = g & 1;
+      r[u] = *(const v4i*)(p.x + ((size_t)b * p.cin + c) * p.Tp + t0 + 16 * half);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = base + u * DEC_NT;
+      if (g < 2 * p.cin_pad) {
+        const int c = g >> 1, half = g & 1;
+        v4i v = r[u];
+        v[0] ^= flip, v[1] ^= flip, v[2] ^= flip, v[3] ^= flip;
+        if (c >= p.cin) v = (v4i){0, 0, 0, 0};
+        *(lds_v4i*)(Xd + c * 32 + 16 * half) = v;
+      }
+    }
   }
   __syncthreads();
   // ---- this wave's share of the K loop

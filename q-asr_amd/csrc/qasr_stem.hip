@@ -75,17 +75,35 @@ __global__ void __launch_bounds__(STEM_NT) k_stem(StemP p) {
   // ---- first-layer QuantAct of the window: input frame of byte i = 2 t0 - padding + i
   const int tin0 = 2 * t0 - p.padding;
   const int lim_in = min(len_in, p.Tx);
-  for (int g = tid; g < p.C * (STEM_XP / 4); g += STEM_NT) {
-    const int c = g / (STEM_XP / 4), i4 = g - c * (STEM_XP / 4);
-    const float* row = p.x + ((size_t)b * p.C + c) * p.Tx;
-    int v[4];
+  {
+    // 64 channels x 28 dwords = 1792 items over 512 threads: all of a thread's loads leave before the first use
+    // (unconditional, from clamped frame indices; a load under a branch is waited for on the spot)
+    constexpr int NI = (STEM_CMAX * (STEM_XP / 4) + STEM_NT - 1) / STEM_NT;
+    const int nitem = p.C * (STEM_XP / 4);
+    float xv[NI][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int ti = tin0 + 4 * i4 + k;
-      const float xv = (ti >= 0 && ti < lim_in) ? row[ti] : 0.0f;          // zero padding and MaskedConv1d's mask
-      v[k] = (int)fminf(fmaxf(rintf(__fmul_rn(p.inv_scale, xv)), (float)p.qlo), (float)p.qhi);
+    for (int u = 0; u < NI; ++u) {
+      const int g = min(tid + u * STEM_NT, nitem - 1);
+      const int c = g / (STEM_XP / 4), i4 = g - c * (STEM_XP / 4);
+      const float* row = p.x + ((size_t)b * p.C + c) * p.Tx;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xv[u][k] = row[min(max(tin0 + 4 * i4 + k, 0), p.Tx - 1)];
     }
-    *(unsigned*)(xq + c * STEM_XP + 4 * i4) = pack4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int g = tid + u * STEM_NT;
+      if (g < nitem) {
+        const int c = g / (STEM_XP / 4), i4 = g - c * (STEM_XP / 4);
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int ti = tin0 + 4 * i4 + k;
+          const float xk = (ti >= 0 && ti < lim_in) ? xv[u][k] : 0.0f;      // zero padding and MaskedConv1d's mask
+          v[k] = (int)fminf(fmaxf(rintf(__fmul_rn(p.inv_scale, xk)), (float)p.qlo), (float)p.qhi);
+        }
+        *(unsigned*)(xq + c * STEM_XP + 4 * i4) = pack4(v[0], v[1], v[2], v[3]);
+      }
+    }
   }
   for (int g = tid; g < 128 * 32 / 16; g += STEM_NT) *(v4i*)(xd + 16 * g) = (v4i){0, 0, 0, 0};   // K rows >= C stay zero
   __syncthreads();
