@@ -47,7 +47,7 @@ typedef v4i __attribute__((address_space(3))) lds_v4i;
 #ifndef SEP2_WPE
 #define SEP2_WPE 2                      /* waves per SIMD the register budget is sized for: 2 = one work-group per CU, 256 VGPRs */
 #endif
-#define SEP2_CH 256                     /* channels per staged window chunk */
+#define SEP2_CH 128                     /* channels per depthwise group: 16 per wave */
 
 template <int K, int TT>
 struct Sep2Geo {
@@ -67,16 +67,20 @@ struct Sep2Geo {
   // LDS row pitch: the lanes of one LDS access group read S-byte runs of 4 (b128) / 8 (b64) different rows; an odd
   // multiple of 4 S bytes puts those rows on disjoint banks (a power-of-two pitch made every read 4-way conflicted)
   // (128-frame tiles keep the dense pitch: the conflict-free one would not fit the LDS next to the 64 KiB A image)
-  static constexpr int WP = TT > 64 ? WLEN : ((WLEN + 4 * S - 1) / (4 * S) | 1) * (4 * S);
+#ifndef SEP2_CF128
+#define SEP2_CF128 1                    /* conflict-free window pitch at 128 frames too: the wave-private rows fit */
+#endif
+  static constexpr int WP = (TT > 64 && !SEP2_CF128) ? WLEN : ((WLEN + 4 * S - 1) / (4 * S) | 1) * (4 * S);
   static constexpr int NPG = WLEN / 16;                  // 16-B granules per row
-  static constexpr int NPT = (SEP2_CH * NPG + SEP2_NT - 1) / SEP2_NT;   // window granules per thread and chunk
+  static constexpr int NPT = (16 * NPG + 63) / 64;       // window granules per lane and group (a wave stages its own 16 rows)
   static constexpr int KP4 = (K + 3) / 4;
   static constexpr int KS = 4 * KP4 + 32;                // row pitch of the zero-margined tap array (pack.py)
-  static constexpr int TAPB = SEP2_CH * KS;              // tap bytes of a chunk (256 KS is a multiple of 16)
-  static constexpr int NTT = (TAPB / 16 + SEP2_NT - 1) / SEP2_NT;       // tap granules per thread and chunk
+  static constexpr int TAPB = 16 * KS;                   // tap bytes of a wave's 16 rows (KS granules of 16 B)
+  static constexpr int NTT = (KS + 63) / 64;             // tap granules per lane and group
+  static constexpr int WREG = 16 * WP + TAPB + 64;       // LDS bytes of one wave's private window + tap rows
   static_assert(3 * S + (A0 & ~(RG - 1)) + NRD * RG <= WLEN && WLEN <= WP, "lane stream leaves the window row");
   static_assert(8 + MS - 3 >= 0 && 8 + MS + 4 * (NS + 1) <= KS, "tap stream leaves the tap row");
-  static_assert(TAPB % 16 == 0, "tap chunk is not 16-byte granular");
+  static_assert(WREG % 16 == 0, "wave regions are not 16-byte granular");
 };
 
 __device__ __forceinline__ int rq_clamp(int z, double M, int lo, int hi) { return med3i(rq_rint(z, M), lo, hi); }
@@ -137,6 +141,26 @@ __device__ __forceinline__ void sep2_gemm(v16i (&acc)[MT], v4i (&wf)[16], const 
         if (r1) sep2_load_wg(&wf[4 * g], r1 + 256 * g);
       }
     }
+  }
+}
+
+// Dwords [D, NE) of a lane's RG-aligned window stream, in the widest aligned LDS reads that cover EXACTLY those dwords:
+// a register of a wider read that nothing uses is handed out again at once, and the write to it waits for the read
+// (an s_waitcnt lgkmcnt(0) in front of the requantisation the read should hide behind).
+template <int D, int NE, int RG>
+__device__ __forceinline__ void sep2_rd_stream(unsigned* xs, const lds_u8* wr) {
+  if constexpr (D < NE) {
+    constexpr int n = (RG == 16 && D % 4 == 0 && NE - D >= 4) ? 4 : (D % 2 == 0 && NE - D >= 2) ? 2 : 1;
+    if constexpr (n == 4) {
+      const v4i v = *(const lds_v4i*)(wr + 4 * D);
+      xs[D] = v[0]; xs[D + 1] = v[1]; xs[D + 2] = v[2]; xs[D + 3] = v[3];
+    } else if constexpr (n == 2) {
+      const v2i v = *(const lds_v2i*)(wr + 4 * D);
+      xs[D] = v[0]; xs[D + 1] = v[1];
+    } else {
+      xs[D] = *(const lds_u32*)(wr + 4 * D);
+    }
+    sep2_rd_stream<D + n, NE, RG>(xs, wr);
   }
 }
 
@@ -211,8 +235,12 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x, t0 = blockIdx.y * TT;
   lds_u8* const Xd = (lds_u8*)smem;                          // [MT][CIN_PAD][32]  A image of the 1x1 conv
-  lds_u8* const Tl = Xd + TT * CIN_PAD;                      // [256][KS] tap rows of the current chunk
-  lds_u8* const Ws = Tl + G::TAPB + 64;                      // [<= 256][WP] window chunk; later the residual A image
+  // depthwise operands are wave-private: wave w stages the window and tap rows of ITS 16 channels of a group in its own
+  // region [16][WP] + [16][KS] - no work-group barrier before the A image is complete; afterwards the region holds the
+  // residual A image
+  lds_u8* const Un = Xd + TT * CIN_PAD;
+  lds_u8* const Wsw = Un + wave * G::WREG;
+  lds_u8* const Tlw = Wsw + 16 * G::WP;
 
   const unsigned flags = e.flags;
   const int eT = e.T, eTp = e.Tp, ecout = e.cout, n_outs = e.n_outs;
@@ -221,7 +249,10 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   const int dlim = min(len_b, eT);                           // the 1x1 conv's MaskedConv1d masks its input
   const bool f_relu = flags & QASR_F_RELU;
   const bool f_exact = flags & QASR_F_EXACT_Z;
-  const int dw_lo = p.dw_lo, dw_hi = p.dw_hi;
+  int dw_lo = p.dw_lo, dw_hi = p.dw_hi;
+  // fetched NOW: left to the compiler the scalar load sits in front of the first requantisation, and its
+  // s_waitcnt lgkmcnt(0) (scalar loads return out of order) also waits for the next group's LDS reads issued just before
+  asm volatile("" : "+s"(dw_lo), "+s"(dw_hi));
   const bool stamp = p.prof && p.prof_mode == 0 && blockIdx.x == 0 && blockIdx.y == 1 && tid == 0;
   const bool tline = p.prof && p.prof_mode == 1 && tid == 0;
   long long tl_start = 0, tl_clk = 0;
@@ -245,16 +276,21 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   v4i pc[G::NPT], pt[G::NTT], rr[NRT > 0 ? NRT : 1], wf[16];
   const int co_l = 32 * wave + (lane & 31);                  // row inside a 256-channel pass
   const v4i* const w0 = w_frag(p.w, CIN_PAD, co_l, 0);
-  auto ld_win = [&](int c0, int i) {                         // window granule i of this thread (coalesced 16-B granules)
-    const int pi = tid + SEP2_NT * i;
-    const int row = pi / G::NPG, col = pi - row * G::NPG;
-    const int t = t0 - G::HALO + 16 * col;                   // a granule lies entirely inside or outside [0, Tp)
-    // unconditional load from a clamped address (commit() zeroes what lies outside): a load under a branch with a
-    // zero-initialised destination is waited for on the spot
-    pc[i] = *(const v4i*)(p.x + ((size_t)b * CIN_PAD + c0 + min(row, SEP2_CH - 1)) * eTp + min(max(t, 0), eTp - 16));
-  };
-  auto ld_tap = [&](int c0, int i) {                         // the chunk's zero-margined tap rows, ONCE per work-group
-    pt[i] = *(const v4i*)((const unsigned char*)p.wdw2 + (size_t)c0 * G::KS + 16 * min(tid + SEP2_NT * i, G::TAPB / 16 - 1));
+  // window + tap rows of this wave's 16 channels of group g (channels 128 g + 16 wave ..): 16-B granules, lane-contiguous
+  auto ld_grp = [&](int g) {
+    const int cw = SEP2_CH * g + 16 * wave;
+#pragma unroll
+    for (int i = 0; i < G::NPT; ++i) {
+      const int pi = lane + 64 * i;
+      const int row = pi / G::NPG, col = pi - row * G::NPG;
+      const int t = t0 - G::HALO + 16 * col;                 // a granule lies entirely inside or outside [0, Tp)
+      // unconditional load from a clamped address (commit() zeroes what lies outside): a load under a branch with a
+      // zero-initialised destination is waited for on the spot
+      pc[i] = *(const v4i*)(p.x + ((size_t)b * CIN_PAD + cw + min(row, 15)) * eTp + min(max(t, 0), eTp - 16));
+    }
+#pragma unroll
+    for (int i = 0; i < G::NTT; ++i)                         // zero-margined tap rows [C][KS]: 16 rows = KS granules
+      pt[i] = *(const v4i*)((const unsigned char*)p.wdw2 + (size_t)cw * G::KS + 16 * min(lane + 64 * i, G::KS - 1));
   };
   auto ld_res = [&](int i) {                                 // residual operand granule: channel gi / (TT/16), 16 frames
     if constexpr (RES) {
@@ -263,36 +299,36 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
       rr[i] = *(const v4i*)(p.panes[0].x + ((size_t)b * PCIN_PAD + c) * eTp + t0 + 16 * q);
     }
   };
-  // request list of depthwise chunk CH: [window + taps of chunk CH+1] [residual operand, last chunk] [weight slab, chunk 0]
+  // request list of depthwise group CH besides the next group's operands: [residual operand, last group] [this group's
+  // share of the weight slab of GEMM pass 0]
+  constexpr int SLC = NCHUNK >= 4 ? 3 : 1;                   // groups the slab's requests are spread over
   auto pf = [&](auto chc, int lo, int hi) {
     constexpr int CH = decltype(chc)::value;
-    constexpr int n_win = CH + 1 < NCHUNK ? G::NPT : 0, n_tap = CH + 1 < NCHUNK ? G::NTT : 0;
-    constexpr int n_res = CH + 1 == NCHUNK ? NRT : 0, n_slab = CH == 0 ? 4 * NG : 0;
+    constexpr int n_res = CH + 1 == NCHUNK ? NRT : 0;
+    constexpr int s0 = CH < SLC ? 4 * NG * CH / SLC : 0, n_slab = CH < SLC ? 4 * NG * (CH + 1) / SLC - s0 : 0;
 #pragma unroll
     for (int i = lo; i < hi; ++i) {
-      if (i < n_win) ld_win(SEP2_CH * (CH + 1), i);
-      else if (i < n_win + n_tap) ld_tap(SEP2_CH * (CH + 1), i - n_win);
-      else if (i < n_win + n_tap + n_res) ld_res(i - n_win - n_tap);
-      else if (i < n_win + n_tap + n_res + n_slab) wf[i - n_win - n_tap - n_res] = w0[64 * (i - n_win - n_tap - n_res)];
+      if (i < n_res) ld_res(i);
+      else if (i < n_res + n_slab) wf[s0 + i - n_res] = w0[64 * (s0 + i - n_res)];
     }
   };
-  auto commit = [&](int c0) {                                // registers -> LDS
+  auto commit = [&]() {                                      // registers -> this wave's LDS rows
 #pragma unroll
     for (int i = 0; i < G::NPT; ++i) {
-      const int pi = tid + SEP2_NT * i;
+      const int pi = lane + 64 * i;
       const int row = pi / G::NPG, col = pi - row * G::NPG;
-      if (row < SEP2_CH) {
+      if (row < 16) {
         const int t = t0 - G::HALO + 16 * col;
         const unsigned keep = (t >= 0 && t < eTp) ? 0xffffffffu : 0u;      // conv zero padding beyond the tensor
         v4i v = pc[i];
         v[0] = (v[0] & keep) ^ flip; v[1] = (v[1] & keep) ^ flip; v[2] = (v[2] & keep) ^ flip; v[3] = (v[3] & keep) ^ flip;
-        *(lds_v4i*)(Ws + row * G::WP + 16 * col) = v;
+        *(lds_v4i*)(Wsw + row * G::WP + 16 * col) = v;
       }
     }
 #pragma unroll
     for (int i = 0; i < G::NTT; ++i) {
-      const int gi = tid + SEP2_NT * i;
-      if (16 * gi < G::TAPB) *(lds_v4i*)(Tl + 16 * gi) = pt[i];
+      const int gi = lane + 64 * i;
+      if (gi < G::KS) *(lds_v4i*)(Tlw + 16 * gi) = pt[i];
     }
   };
   // K == 0 (a bare 1x1 conv, e.g. block 17 of QuartzNet): no depthwise stage - the [channel][frame] tile of `x` IS the
@@ -309,28 +345,26 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
 #pragma unroll
     for (int j = 0; j < 4 * NG; ++j) wf[j] = w0[64 * j];       // the whole first slab right behind the tile
   } else {
-#pragma unroll
-    for (int i = 0; i < G::NPT; ++i) ld_win(0, i);
-#pragma unroll
-    for (int i = 0; i < G::NTT; ++i) ld_tap(0, i);
+    ld_grp(0);
   }
-  STAMP2();                                                  // requests of chunk 0 issued
+  STAMP2();                                                  // requests of group 0 issued
 
   // per-group depthwise parameters of this lane's channels and the per-lane parameters of every GEMM pass: a handful
   // of registers, requested right behind chunk 0
   const int cb = lane >> 2, jl = lane & 3;
-  int dbias[2 * NCHUNK];
-  double dM[2 * NCHUNK];
+  int dbias[NCHUNK];
+  double dM[NCHUNK];
   if constexpr (K > 0) {
 #pragma unroll
-    for (int gi = 0; gi < 2 * NCHUNK; ++gi) {
-      const int c = SEP2_CH * (gi >> 1) + 32 * wave + 16 * (gi & 1) + cb;
+    for (int gi = 0; gi < NCHUNK; ++gi) {
+      const int c = SEP2_CH * gi + 16 * wave + cb;           // a wave owns 16 channels of every chunk
       dbias[gi] = p.bias_dw[c];
       dM[gi] = p.m_dw[c];
     }
   }
   Sep2PassP pps[NP];
-#pragma unroll
+  auto load_pps = [&]() {                                    // (issued behind the first group's operands: not on the way
+#pragma unroll                                               //  to the first MFMA)
   for (int ps = 0; ps < NP; ++ps) {
     const int cor = 256 * ps + co_l;
     Sep2PassP& q = pps[ps];
@@ -346,6 +380,8 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
     }
     q.sbm = f_exact ? e.sb[cor] : 1.0f;
   }
+  };
+  if constexpr (K == 0) load_pps();
 
   // ------------------------------------------------------------------------------------------ depthwise stage
   // v_mfma_i32_4x4x4_16B_i8: 16 independent 4x4x4 products, block = channel.  A[i][k] = w[m0 + k - i] (lane i's own
@@ -359,30 +395,19 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
     unsigned raw[NS + 1];                                    // the lane's tap dwords (whole words, funnel-shifted later)
     unsigned xs[G::NRD * (G::RG / 4)];                       // the lane's window run: every dword feeds the NU chains
   };
-  auto dw_read = [&](DwIn& in, int g) {
-    const int row = 32 * wave + 16 * g + cb;
-    const lds_u32* tr = (const lds_u32*)(Tl + row * G::KS + 4 * tq);
+  auto dw_read = [&](DwIn& in) {                             // this wave's 16 channels: row = channel, lane (cb, jl)
+    const int row = cb;
+    const lds_u32* tr = (const lds_u32*)(Tlw + row * G::KS + 4 * tq);
 #pragma unroll
     for (int i = 0; i <= NS; ++i) in.raw[i] = tr[i];
-    const lds_u8* wr = Ws + row * G::WP + S * jl + (G::A0 & ~(G::RG - 1));
-#pragma unroll
-    for (int i = 0; i < G::NRD; ++i) {
-      if constexpr (G::RG == 16) {
-        const v4i v = *(const lds_v4i*)(wr + 16 * i);
-        in.xs[4 * i] = v[0]; in.xs[4 * i + 1] = v[1]; in.xs[4 * i + 2] = v[2]; in.xs[4 * i + 3] = v[3];
-      } else {
-        const v2i v = *(const lds_v2i*)(wr + 8 * i);
-        in.xs[2 * i] = v[0]; in.xs[2 * i + 1] = v[1];
-      }
-    }
+    const lds_u8* wr = Wsw + row * G::WP + S * jl + (G::A0 & ~(G::RG - 1));
+    sep2_rd_stream<G::OFF, G::NE, G::RG>(in.xs, wr);
   };
-  // the math of one group; `pf3(k)` issues the k-th third of the group's share of the request list
-  auto dw_math = [&](const DwIn& in, int c0, int g, int bias, double Mg, auto&& pf3) {
-    const int c = c0 + 32 * wave + 16 * g + cb;
+  // the MFMAs of one group; `pf3(k)` issues the k-th third of the group's request list
+  auto dw_mfma = [&](const DwIn& in, v4i (&acc)[NU], int bias, auto&& pf3) {
     unsigned tw[NS];
 #pragma unroll
     for (int st = 0; st < NS; ++st) tw[st] = __builtin_amdgcn_alignbyte(in.raw[st + 1], in.raw[st], tsh);
-    v4i acc[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) acc[u] = (v4i){bias, bias, bias, bias};
     pf3(0);
@@ -394,6 +419,10 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
         acc[u] = __builtin_amdgcn_mfma_i32_4x4x4i8((int)tw[st], (int)in.xs[G::OFF + u + st], acc[u], 0, 0, 0);
     }
     pf3(2);
+  };
+  // masks, requantisation and the [channel][frame] image of one group
+  auto dw_out = [&](v4i (&acc)[NU], int c0, double Mg) {
+    const int c = c0 + 16 * wave + cb;
     if (DBG && p.dw_acc_dbg) {
 #pragma unroll
       for (int u = 0; u < NU; ++u)
@@ -421,44 +450,46 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
     }
   };
 
+  // Depthwise operands are wave-private, so nothing in this stage involves another wave: the two waves of a SIMD drift
+  // apart and one's MFMAs run beside the other's requantisation / LDS traffic / waits (with work-group barriers between
+  // 256-channel chunks every wave waited ~1.4 k cycles per barrier for its SIMD partner's MFMAs - phase stamps).
+  // Software pipeline of a wave: MFMAs of group g | rows of group g+1 -> LDS, request group g+2, read the lane streams of
+  // g+1 back (the LDS round trip runs under:) | requantisation of group g | MFMAs of group g+1 ...
+  DwIn in;
+  auto stage = [&](auto chc) {                               // rows of group CH: registers -> LDS -> lane streams
+    constexpr int CH = decltype(chc)::value;
+    commit();
+    if constexpr (CH + 1 < NCHUNK) ld_grp(CH + 1);
+    // the wave's own LDS writes -> its own reads: LDS executes a wave's instructions in order; the fences keep the
+    // compiler from moving the reads above the writes of other lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    dw_read(in);
+    __builtin_amdgcn_sched_barrier(0);                       // the reads are issued here; their first use is the next group
+  };
   auto chunk = [&](auto chc) {
     constexpr int CH = decltype(chc)::value;
     constexpr int c0 = SEP2_CH * CH;
-    constexpr int NPF = (CH + 1 < NCHUNK ? G::NPT + G::NTT : 0) + (CH + 1 == NCHUNK ? NRT : 0) + (CH == 0 ? 4 * NG : 0);
-    constexpr int Q = (NPF + 5) / 6;                         // six issue points per chunk
-    if (CH) __syncthreads();                                 // previous chunk's window and taps fully consumed
-    if (stamp) {                                             // diagnostics: when did this wave's window / taps land?
+    constexpr int NPF = (CH + 1 == NCHUNK ? NRT : 0) + (CH < SLC ? 4 * NG * (CH + 1) / SLC - 4 * NG * CH / SLC : 0);
+    constexpr int Q = (NPF + 2) / 3;                         // three issue points per group
+    v4i acc[NU];
+    dw_mfma(in, acc, dbias[CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
+    STAMP2();
+    if constexpr (CH + 1 < NCHUNK) stage(std::integral_constant<int, CH + 1>{});
+    dw_out(acc, c0, dM[CH]);
+    __builtin_amdgcn_sched_barrier(0);                       // (keeps the next group's tap-stream shifts - the first use of
+    STAMP2();                                                //  the reads above - behind this group's requantisation)
+  };
+  if constexpr (K > 0) {
+    if (stamp) {                                             // diagnostics: when did group 0's window / taps land?
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       STAMP2();
     }
-    commit(c0);
+    stage(std::integral_constant<int, 0>{});
+    load_pps();
     STAMP2();
-    __syncthreads();
-    if (CH == 0) {
-      // every load issued so far has landed (commit waited for the window); re-define the early per-lane parameters so
-      // that their later uses do not wait for the requests issued from here on
-#pragma unroll
-      for (int gi = 0; gi < 2 * NCHUNK; ++gi) asm volatile("" : "+v"(dbias[gi]), "+v"(dM[gi]));
-    }
-    STAMP2();
-    if constexpr (TT > 64) {                                 // register budget: one operand set at a time
-      DwIn in;
-      dw_read(in, 0);
-      dw_math(in, c0, 0, dbias[2 * CH], dM[2 * CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
-      dw_read(in, 1);
-      dw_math(in, c0, 1, dbias[2 * CH + 1], dM[2 * CH + 1], [&](int k) { pf(chc, Q * (3 + k), Q * (4 + k)); });
-    } else {                                                 // both groups' LDS operands in flight before the first MFMA
-      DwIn inA, inB;
-      dw_read(inA, 0);
-      dw_read(inB, 1);
-      dw_math(inA, c0, 0, dbias[2 * CH], dM[2 * CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
-      dw_math(inB, c0, 1, dbias[2 * CH + 1], dM[2 * CH + 1], [&](int k) { pf(chc, Q * (3 + k), Q * (4 + k)); });
-    }
-    STAMP2();
-  };
-  if constexpr (K > 0) {
-    chunk(std::integral_constant<int, 0>{});
-    if constexpr (NCHUNK > 1) chunk(std::integral_constant<int, 1>{});
+    sep2_for<0, NCHUNK>([&](auto chc) { chunk(chc); });
   } else {
     static_assert(K > 0 || !RES, "the bare 1x1 form has no residual variant");
     const unsigned xflip = p.pw_unsigned ? 0x80808080u : 0u;
@@ -471,8 +502,8 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
       *(lds_v4i*)(Xd + (q >> 1) * (CIN_PAD * 32) + c * 32 + 16 * (q & 1)) = v;
     }
   }
-  static_assert(NCHUNK <= 2, "more than 512 input channels");
-  __syncthreads();                                           // Xd complete, window dead
+  static_assert(NCHUNK <= 4, "more than 512 input channels");
+  __syncthreads();                                           // Xd complete, windows dead
   if constexpr (RES) {                                       // residual A image [PCIN_PAD][32] per 32-frame tile
     const unsigned rflip = p.panes[0].x_unsigned ? 0x80808080u : 0u;
 #pragma unroll
@@ -481,7 +512,7 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
       const int c = gi / (TT / 16), q = gi - c * (TT / 16);
       v4i v = rr[i];
       v[0] ^= rflip; v[1] ^= rflip; v[2] ^= rflip; v[3] ^= rflip;
-      *(lds_v4i*)(Ws + (q >> 1) * (PCIN_PAD * 32) + c * 32 + 16 * (q & 1)) = v;
+      *(lds_v4i*)(Un + (q >> 1) * (PCIN_PAD * 32) + c * 32 + 16 * (q & 1)) = v;
     }
     __syncthreads();
   }
@@ -489,7 +520,7 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
 
   // ------------------------------------------------------------------------------------------ 1x1 GEMM passes of 256 channels
   const lds_u8* const xd_lane = Xd + sep2_a_lane_off(lane);
-  const lds_u8* const xr_lane = Ws + sep2_a_lane_off(lane);
+  const lds_u8* const xr_lane = Un + sep2_a_lane_off(lane);
   const bool full_out = t0 + TT <= lim;
   int32_t* const pdbg = RES ? p.panes[0].acc_dbg : nullptr;
   const int qlo = f_relu ? max(e.qlo, 0) : e.qlo, qhi = e.qhi;
@@ -724,9 +755,9 @@ static inline size_t sep2_smem_bytes(const SepP& p) {
   using G = Sep2Geo<K, TT>;
   const size_t xd = (size_t)TT * p.cin_pad;
   if (K == 0) return xd;
-  size_t ws = (size_t)std::min(SEP2_CH, p.cin) * G::WP + 64;
-  if (p.n_panes == 1) ws = std::max(ws, (size_t)TT * p.panes[0].cin_pad);
-  return xd + G::TAPB + 64 + ws;
+  size_t un = (size_t)(SEP2_NT / 64) * G::WREG;                                 // the waves' private window + tap rows
+  if (p.n_panes == 1) un = std::max(un, (size_t)TT * p.panes[0].cin_pad);       // later: the residual A image
+  return xd + un;
 }
 
 // (taps, cin groups, residual cin groups) k_sep2 is instantiated for: QuartzNet's separable layers (256 / 512 channels);
