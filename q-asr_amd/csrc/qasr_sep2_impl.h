@@ -29,6 +29,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "qasr_device.h"
@@ -252,9 +253,10 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   int dw_lo = p.dw_lo, dw_hi = p.dw_hi;
   // fetched NOW: left to the compiler the scalar load sits in front of the first requantisation, and its
   // s_waitcnt lgkmcnt(0) (scalar loads return out of order) also waits for the next group's LDS reads issued just before
-  asm volatile("" : "+s"(dw_lo), "+s"(dw_hi));
-  const bool stamp = p.prof && p.prof_mode == 0 && blockIdx.x == 0 && blockIdx.y == 1 && tid == 0;
-  const bool tline = p.prof && p.prof_mode == 1 && tid == 0;
+  asm volatile("" : "+v"(dw_lo), "+v"(dw_hi));               // (as VGPRs: v_med3_i32's operands; "+s" breaks the debug build)
+  const bool stamp = p.prof && (p.prof_mode & 255) == 0 && blockIdx.x == 0 && blockIdx.y == 1 && tid == 0;
+  const bool tline = p.prof && (p.prof_mode & 255) == 1 && tid == 0;
+  const int tune = p.prof_mode >> 8;                          // QASR_SEP2_TUNE (experiments)
   long long tl_start = 0, tl_clk = 0;
   if (tline) {
     tl_start = (long long)__builtin_amdgcn_s_memrealtime();
@@ -391,6 +393,15 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   const bool full_in = t0 + TT <= dlim;                      // no masked frame in this tile (uniform)
   constexpr int e0base = 8 + G::MS;                          // the lane's tap stream starts at byte e0base - jl of its row
   const int e0 = e0base - jl, tq = e0 >> 2, tsh = e0 & 3;
+  unsigned fmask[NU];                                        // bytes of output dword u that lie below the utterance's length
+  {
+    const int dl = dlim - t0 - S * jl;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int n = min(max(dl - 4 * u, 0), 4);
+      fmask[u] = n >= 4 ? 0xffffffffu : ((1u << (8 * n)) - 1u);
+    }
+  }
   struct DwIn {                                              // LDS operands of one group of 16 channels
     unsigned raw[NS + 1];                                    // the lane's tap dwords (whole words, funnel-shifted later)
     unsigned xs[G::NRD * (G::RG / 4)];                       // the lane's window run: every dword feeds the NU chains
@@ -432,22 +443,63 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
           if (t0 + f < eT) p.dw_acc_dbg[((size_t)b * CIN_PAD + c) * eTp + t0 + f] = acc[u][v];
         }
     }
-    if (!full_in) {                                          // masked frames (t >= len): accumulator 0 requantises to 0
-      int dl = dlim - t0 - S * jl;                           // (dw_lo <= 0 <= dw_hi); kept out of the loop-invariant code
-      asm volatile("" : "+v"(dl));
-#pragma unroll
-      for (int u = 0; u < NU; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          if (4 * u + v >= dl) acc[u][v] = 0;
-    }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int f = S * jl + 4 * u;                          // first of this dword's 4 frames
       const unsigned w = pack4b(rq_clamp(acc[u][0], Mg, dw_lo, dw_hi), rq_clamp(acc[u][1], Mg, dw_lo, dw_hi),
                                 rq_clamp(acc[u][2], Mg, dw_lo, dw_hi), rq_clamp(acc[u][3], Mg, dw_lo, dw_hi));
-      *(lds_u32*)(Xd + (f >> 5) * (CIN_PAD * 32) + c * 32 + (f & 31)) = w;
+      // masked frames (t >= len): code 0 (= what a zeroed accumulator requantises to, dw_lo <= 0 <= dw_hi) - one AND per
+      // dword with the lane's precomputed byte masks, branch-free, so that this block can be interleaved with MFMAs
+      *(lds_u32*)(Xd + (f >> 5) * (CIN_PAD * 32) + c * 32 + (f & 31)) = w & fmask[u];
     }
+  };
+
+  // MFMAs of one group with ONE instruction of the previous group's output work (dw_out, spelled out as single
+  // instructions: cvt / fma / med3 per value, perm / perm / or / and / ds_write per dword) pinned behind each MFMA
+  auto dw_mfma_ilv = [&](const DwIn& in, v4i (&acc)[NU], int bias, auto&& pf3, v4i (&prev)[NU], int cprev, double Mprev) {
+    constexpr int NOPS = 17 * NU, OPM = (NOPS + NS * NU - 1) / (NS * NU);   // instructions behind each MFMA (1; 2 for k33 / k39)
+    const int c = cprev + 16 * wave + cb;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) acc[u] = (v4i){bias, bias, bias, bias};
+    unsigned tw = 0, P1 = 0, P2 = 0;
+    double dreg = 0.0;
+    int q[4] = {0, 0, 0, 0};
+    __builtin_amdgcn_sched_barrier(0);
+    sep2_for<0, NS * NU>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, st = i / NU, u = i % NU;
+      if constexpr (u == 0) {
+        if constexpr (st == 0) pf3(0);
+        if constexpr (st == NS / 2) pf3(1);
+        tw = __builtin_amdgcn_alignbyte(in.raw[st + 1], in.raw[st], tsh);
+      }
+      acc[u] = __builtin_amdgcn_mfma_i32_4x4x4i8((int)tw, (int)in.xs[G::OFF + u + st], acc[u], 0, 0, 0);
+      sep2_for<OPM * i, OPM * (i + 1)>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j < NOPS) {
+        constexpr int dw = j / 17, r = j % 17;
+        if constexpr (r < 12) {
+          constexpr int val = r / 3, ph = r % 3;
+          if constexpr (ph == 0) dreg = (double)prev[dw][val];
+          if constexpr (ph == 1) dreg = __builtin_fma(dreg, Mprev, MAGIC_RNE);
+          if constexpr (ph == 2) q[val] = med3i(__double2loint(dreg), dw_lo, dw_hi);
+        } else if constexpr (r == 12) {
+          P1 = __builtin_amdgcn_perm((unsigned)q[1], (unsigned)q[0], 0x0c0c0400u);
+        } else if constexpr (r == 13) {
+          P2 = __builtin_amdgcn_perm((unsigned)q[3], (unsigned)q[2], 0x04000c0cu);
+        } else if constexpr (r == 14) {
+          P1 |= P2;
+        } else if constexpr (r == 15) {
+          P1 &= fmask[dw];
+        } else {
+          constexpr int f0 = 4 * dw;                         // frame S jl + 4 dw: tile (S jl + 4 dw) >> 5, column & 31
+          const int f = S * jl + f0;
+          *(lds_u32*)(Xd + (f >> 5) * (CIN_PAD * 32) + c * 32 + (f & 31)) = P1;
+        }
+      }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    pf3(2);
   };
 
   // Depthwise operands are wave-private, so nothing in this stage involves another wave: the two waves of a SIMD drift
@@ -468,26 +520,61 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
     dw_read(in);
     __builtin_amdgcn_sched_barrier(0);                       // the reads are issued here; their first use is the next group
   };
+  // The SIMD issues one VALU or MFMA instruction per ~4.6 cycles whichever wave it comes from, a 4x4x4 MFMA occupies the
+  // matrix pipe for 8.3, and the older wave of a SIMD pair wins every issue slot it can use (profiles/microbench/
+  // coissue.hip: two waves alternating 168 MFMAs / 240 VALU instructions take exactly the sum of their times) - VALU work
+  // hides only in the shadow of the SAME wave's MFMAs.  So the requantisation of group g-1 (independent of group g's
+  // MFMAs) is issued one instruction behind every MFMA of group g (dw_mfma_ilv; a sched_group_barrier pipeline over
+  // dw_mfma + dw_out hoisted all 21 tap-stream shifts, spilled, and placed a VALU instruction only every ~20 MFMAs).
+#ifndef SEP2_ILV
+#define SEP2_ILV 1
+#endif
+  constexpr bool ILV = SEP2_ILV && (!RES || TT <= 64);       // (register budget of the block-end forms at 128 frames)
+  v4i accs[ILV ? 2 : 1][NU];
   auto chunk = [&](auto chc) {
     constexpr int CH = decltype(chc)::value;
     constexpr int c0 = SEP2_CH * CH;
     constexpr int NPF = (CH + 1 == NCHUNK ? NRT : 0) + (CH < SLC ? 4 * NG * (CH + 1) / SLC - 4 * NG * CH / SLC : 0);
     constexpr int Q = (NPF + 2) / 3;                         // three issue points per group
-    v4i acc[NU];
-    dw_mfma(in, acc, dbias[CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
-    STAMP2();
-    if constexpr (CH + 1 < NCHUNK) stage(std::integral_constant<int, CH + 1>{});
-    dw_out(acc, c0, dM[CH]);
-    __builtin_amdgcn_sched_barrier(0);                       // (keeps the next group's tap-stream shifts - the first use of
-    STAMP2();                                                //  the reads above - behind this group's requantisation)
+    if constexpr (ILV) {
+      if constexpr (CH == 0) dw_mfma(in, accs[0], dbias[0], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
+      else {
+        if (DBG && p.dw_acc_dbg) {                           // (debug builds: the plain order, accumulators dumped)
+          dw_out(accs[(CH - 1) & 1], c0 - SEP2_CH, dM[CH - 1]);
+          dw_mfma(in, accs[CH & 1], dbias[CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
+        } else {
+          dw_mfma_ilv(in, accs[CH & 1], dbias[CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); }, accs[(CH - 1) & 1],
+                      c0 - SEP2_CH, dM[CH - 1]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP2();
+      if constexpr (CH + 1 < NCHUNK) stage(std::integral_constant<int, CH + 1>{});
+      else dw_out(accs[CH & 1], c0, dM[CH]);
+      STAMP2();
+    } else {
+      dw_mfma(in, accs[0], dbias[CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
+      STAMP2();
+      if constexpr (CH + 1 < NCHUNK) stage(std::integral_constant<int, CH + 1>{});
+      dw_out(accs[0], c0, dM[CH]);
+      __builtin_amdgcn_sched_barrier(0);                     // (keeps the next group's tap-stream shifts - the first use of
+      STAMP2();                                              //  the reads above - behind this group's requantisation)
+    }
   };
   if constexpr (K > 0) {
     if (stamp) {                                             // diagnostics: when did group 0's window / taps land?
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       STAMP2();
     }
+    if (tune & 1) {                                          // strict priority for one wave of every SIMD pair
+      if (wave < 4) __builtin_amdgcn_s_setprio(3);
+    }
     stage(std::integral_constant<int, 0>{});
     load_pps();
+    if (tune & 2) {                                          // stagger the SIMD partners by (tune >> 4) x 64 cycles
+      if (wave >= 4)
+        for (int i = 0; i < ((tune >> 4) & 127); ++i) __builtin_amdgcn_s_sleep(1);
+    }
     STAMP2();
     sep2_for<0, NCHUNK>([&](auto chc) { chunk(chc); });
   } else {
@@ -503,6 +590,7 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
     }
   }
   static_assert(NCHUNK <= 4, "more than 512 input channels");
+  if ((tune & 5) == 1) __builtin_amdgcn_s_setprio(0);        // (tune & 4: the priority stays through the GEMM passes)
   __syncthreads();                                           // Xd complete, windows dead
   if constexpr (RES) {                                       // residual A image [PCIN_PAD][32] per 32-frame tile
     const unsigned rflip = p.panes[0].x_unsigned ? 0x80808080u : 0u;
@@ -803,7 +891,8 @@ static int launch_sep2_v(hipStream_t s, const SepP& p) {
   }
   SepP q = p;
   q.prof = g_prof;
-  q.prof_mode = g_prof_mode;
+  static const int tune = getenv("QASR_SEP2_TUNE") ? atoi(getenv("QASR_SEP2_TUNE")) : 0;
+  q.prof_mode = g_prof_mode | (tune << 8);
   hipLaunchKernelGGL((k_sep2<K, NG, NGP, NP, DBG, TT>), dim3(p.e.B, p.e.Tp / TT, 1), dim3(SEP2_NT), smem, s, q);
   return QASR_OK;
 }
