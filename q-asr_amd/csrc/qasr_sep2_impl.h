@@ -278,21 +278,34 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   v4i pc[G::NPT], pt[G::NTT], rr[NRT > 0 ? NRT : 1], wf[16];
   const int co_l = 32 * wave + (lane & 31);                  // row inside a 256-channel pass
   const v4i* const w0 = w_frag(p.w, CIN_PAD, co_l, 0);
-  // window + tap rows of this wave's 16 channels of group g (channels 128 g + 16 wave ..): 16-B granules, lane-contiguous
+  // window + tap rows of this wave's 16 channels of group g (channels 128 g + 16 wave ..): 16-B granules, lane-contiguous.
+  // Everything per lane is the same for every group and computed once - byte offsets of its granules from the group's
+  // (wave-uniform) row 0, zero-padding masks, LDS addresses: a group's staging is loads, one bit-op per dword, stores
+  int woff[G::NPT], toff[G::NTT];
+  unsigned wkeep[G::NPT];
+  lds_u8* wlds[G::NPT];
+#pragma unroll
+  for (int i = 0; i < G::NPT; ++i) {
+    const int pi = lane + 64 * i;
+    const int row = pi / G::NPG, col = pi - row * G::NPG;
+    const int t = t0 - G::HALO + 16 * col;                   // a granule lies entirely inside or outside [0, Tp)
+    // unconditional loads from clamped addresses (the keep mask zeroes what lies outside): a load under a branch with a
+    // zero-initialised destination is waited for on the spot
+    woff[i] = min(row, 15) * eTp + min(max(t, 0), eTp - 16);
+    wkeep[i] = (t >= 0 && t < eTp) ? 0xffffffffu : 0u;       // conv zero padding beyond the tensor
+    wlds[i] = Wsw + min(row, 15) * G::WP + 16 * col;
+    asm volatile("" : "+v"(wkeep[i]));                       // a mask, not a predicate: (v & keep) ^ flip is ONE v_bitop3_b32
+  }
+#pragma unroll
+  for (int i = 0; i < G::NTT; ++i) toff[i] = 16 * min(lane + 64 * i, G::KS - 1);
   auto ld_grp = [&](int g) {
-    const int cw = SEP2_CH * g + 16 * wave;
+    const int cw = SEP2_CH * g + 16 * wave;                  // (wave-uniform: the bases below are scalar)
+    const int8_t* const xg = p.x + ((size_t)b * CIN_PAD + cw) * eTp;
+    const unsigned char* const tg = (const unsigned char*)p.wdw2 + (size_t)cw * G::KS;   // zero-margined tap rows [C][KS]
 #pragma unroll
-    for (int i = 0; i < G::NPT; ++i) {
-      const int pi = lane + 64 * i;
-      const int row = pi / G::NPG, col = pi - row * G::NPG;
-      const int t = t0 - G::HALO + 16 * col;                 // a granule lies entirely inside or outside [0, Tp)
-      // unconditional load from a clamped address (commit() zeroes what lies outside): a load under a branch with a
-      // zero-initialised destination is waited for on the spot
-      pc[i] = *(const v4i*)(p.x + ((size_t)b * CIN_PAD + cw + min(row, 15)) * eTp + min(max(t, 0), eTp - 16));
-    }
+    for (int i = 0; i < G::NPT; ++i) pc[i] = *(const v4i*)(xg + woff[i]);
 #pragma unroll
-    for (int i = 0; i < G::NTT; ++i)                         // zero-margined tap rows [C][KS]: 16 rows = KS granules
-      pt[i] = *(const v4i*)((const unsigned char*)p.wdw2 + (size_t)cw * G::KS + 16 * min(lane + 64 * i, G::KS - 1));
+    for (int i = 0; i < G::NTT; ++i) pt[i] = *(const v4i*)(tg + toff[i]);
   };
   auto ld_res = [&](int i) {                                 // residual operand granule: channel gi / (TT/16), 16 frames
     if constexpr (RES) {
@@ -317,20 +330,16 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   auto commit = [&]() {                                      // registers -> this wave's LDS rows
 #pragma unroll
     for (int i = 0; i < G::NPT; ++i) {
-      const int pi = lane + 64 * i;
-      const int row = pi / G::NPG, col = pi - row * G::NPG;
-      if (row < 16) {
-        const int t = t0 - G::HALO + 16 * col;
-        const unsigned keep = (t >= 0 && t < eTp) ? 0xffffffffu : 0u;      // conv zero padding beyond the tensor
+      if (64 * i + 63 < 16 * G::NPG || lane + 64 * i < 16 * G::NPG) {
         v4i v = pc[i];
-        v[0] = (v[0] & keep) ^ flip; v[1] = (v[1] & keep) ^ flip; v[2] = (v[2] & keep) ^ flip; v[3] = (v[3] & keep) ^ flip;
-        *(lds_v4i*)(Wsw + row * G::WP + 16 * col) = v;
+        v[0] = (v[0] & wkeep[i]) ^ flip; v[1] = (v[1] & wkeep[i]) ^ flip; v[2] = (v[2] & wkeep[i]) ^ flip; v[3] = (v[3] & wkeep[i]) ^ flip;
+        *(lds_v4i*)wlds[i] = v;
       }
     }
 #pragma unroll
     for (int i = 0; i < G::NTT; ++i) {
       const int gi = lane + 64 * i;
-      if (gi < G::KS) *(lds_v4i*)(Tlw + 16 * gi) = pt[i];
+      if (64 * i + 63 < G::KS || gi < G::KS) *(lds_v4i*)(Tlw + 16 * gi) = pt[i];
     }
   };
   // K == 0 (a bare 1x1 conv, e.g. block 17 of QuartzNet): no depthwise stage - the [channel][frame] tile of `x` IS the
@@ -406,12 +415,15 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
     unsigned raw[NS + 1];                                    // the lane's tap dwords (whole words, funnel-shifted later)
     unsigned xs[G::NRD * (G::RG / 4)];                       // the lane's window run: every dword feeds the NU chains
   };
+  // the lane's two LDS streams, each behind a base register of its own: every read is base + immediate offset
+  const lds_u32* tr_lane = (const lds_u32*)(Tlw + cb * G::KS + 4 * tq);
+  const lds_u8* wr_lane = Wsw + cb * G::WP + S * jl + (G::A0 & ~(G::RG - 1));
+  asm volatile("" : "+v"(tr_lane), "+v"(wr_lane));
   auto dw_read = [&](DwIn& in) {                             // this wave's 16 channels: row = channel, lane (cb, jl)
-    const int row = cb;
-    const lds_u32* tr = (const lds_u32*)(Tlw + row * G::KS + 4 * tq);
+    const lds_u32* tr = tr_lane;
 #pragma unroll
     for (int i = 0; i <= NS; ++i) in.raw[i] = tr[i];
-    const lds_u8* wr = Wsw + row * G::WP + S * jl + (G::A0 & ~(G::RG - 1));
+    const lds_u8* wr = wr_lane;
     sep2_rd_stream<G::OFF, G::NE, G::RG>(in.xs, wr);
   };
   // the MFMAs of one group; `pf3(k)` issues the k-th third of the group's request list
