@@ -172,7 +172,7 @@ __device__ __forceinline__ void sep2_for(F&& f) {
     sep2_for<I + 1, N>(f);
   }
 }
-// sep2_gemm with a slice of other work behind every batch of MFMAs: cb(integral_constant<q>), q < 4 N / AB.  The matrix
+// sep2_gemm with a slice of other work behind every MFMA: cb(integral_constant<slot>), slot < 4 N MT.  The matrix
 // pipe runs a 32x32x32 MFMA for 32 cycles while the wave issues the slice's VALU instructions (the previous unit's
 // requantisation); sched_barrier keeps the compiler from gathering the slices behind the last MFMA.
 template <int MT, int N, int N0, int AB, class CB>
@@ -192,11 +192,15 @@ __device__ __forceinline__ void sep2_gemm_cb(v16i (&acc)[MT], v4i (&wf)[16], con
 #pragma unroll
         for (int i = 0; i < AB; ++i) a[(q + 1) & 1][mt][i] = sep2_a_frag(img_lane + mt * mt_stride, AB * (q + 1) + i);
     }
-#pragma unroll
-    for (int i = 0; i < AB; ++i)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q & 1][mt][i], wf[AB * q + i], acc[mt], 0, 0, 0);
+    // one slice behind EVERY MFMA (slot (q AB + i) MT + mt): a wave issues in order, so a longer slice behind a batch of
+    // MFMAs runs past the last MFMA's 32 cycles and the matrix pipe idles until the next batch can issue
+    sep2_for<0, AB * MT>([&](auto sc) {
+      constexpr int sl = decltype(sc)::value, i = sl / MT, mt = sl % MT;
+      acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q & 1][mt][i], wf[AB * q + i], acc[mt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      cb(std::integral_constant<int, q * AB * MT + sl>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
     if constexpr ((AB * (q + 1)) % 4 == 0) {
       constexpr int g = (AB * (q + 1)) / 4 - 1;
       if constexpr (g < N0) {
@@ -205,8 +209,6 @@ __device__ __forceinline__ void sep2_gemm_cb(v16i (&acc)[MT], v4i (&wf)[16], con
         if (r1) sep2_load_wg(&wf[4 * g], r1 + 256 * g);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    cb(qc);
     __builtin_amdgcn_sched_barrier(0);
   });
 }
@@ -632,7 +634,7 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   if constexpr (PIPED) {
     {
       constexpr int MH = MT >= 2 ? MT / 2 : 1, NH = MT / MH, NUN = NP * NH;   // tiles per unit, units per pass, units
-      constexpr int AB = MH >= 2 ? 1 : 2, NQ = 4 * NG / AB, NV = 16 * MH, VPS = (NV + NQ - 1) / NQ;   // (register budget at MH = 2)
+      constexpr int AB = MH >= 2 ? 1 : 2, NSL = 4 * NG * MH, NV = 16 * MH, VPS = (NV + NSL - 1) / NSL;   // (AB: register budget at MH = 2)
       const OutP& o0 = e.outs[0];
       const int olo = o0.lo, ohi = o0.hi;
       int8_t* const optr = (int8_t*)o0.ptr;
@@ -701,7 +703,7 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
         if constexpr (u > 0) unit_finish(accs[(u - 1) & 1], (u - 1) / NH, ((u - 1) % NH) * MH);
         sep2_gemm_cb<MH, NG, 0, AB>(cur, wf, xd_lane + hf * MH * (CIN_PAD * 32), CIN_PAD * 32, nullptr, wnext, [&](auto qc) {
           if constexpr (u > 0) {
-            constexpr int q = decltype(qc)::value, v0 = q * VPS < NV ? q * VPS : NV, v1 = (q + 1) * VPS < NV ? (q + 1) * VPS : NV;
+            constexpr int q = decltype(qc)::value, v0 = q * VPS < NV ? q * VPS : NV, v1 = (q + 1) * VPS < NV ? (q + 1) * VPS : NV;   // q: MFMA slot
             unit_values(accs[(u - 1) & 1], (u - 1) / NH, ((u - 1) % NH) * MH, std::integral_constant<int, v0>{},
                         std::integral_constant<int, v1>{});
           }
