@@ -165,6 +165,32 @@ __device__ __forceinline__ void sep2_rd_stream(unsigned* xs, const lds_u8* wr) {
   }
 }
 
+// 16 consecutive output frames of a lane as 4 packed dwords: keep the first n (any int), zero the rest.  Masked frames
+// (t >= len) are code 0 for every consumer - what a zeroed accumulator requantises to (lo <= 0 <= hi, also through
+// res_act) - so the mask is applied to the packed codes of the ONE tile per utterance that straddles the length
+// (a uniform branch) instead of to every accumulator of a partial work-group (64 + 64 VALU instructions per pass).
+__device__ __forceinline__ v4i sep2_mask16(v4i pk, int n) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = min(max(n - 4 * i, 0), 4);
+    pk[i] &= m >= 4 ? -1 : (int)((1u << (8 * m)) - 1u);
+  }
+  return pk;
+}
+// does any accumulator leave [-2^21, 2^21)?  (v_max3 / v_min3: one instruction per two values and bound)
+template <int MT>
+__device__ __forceinline__ bool sep2_any_wide(const v16i (&a)[MT]) {
+  int mx = a[0][0], mn = a[0][0];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      mx = max(max(mx, a[mt][r]), a[mt][r + 1]);
+      mn = min(min(mn, a[mt][r]), a[mt][r + 1]);
+    }
+  return __any(mx >= (1 << 21) || mn < -(1 << 21));
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void sep2_for(F&& f) {
   if constexpr (I < N) {
@@ -623,7 +649,6 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   // ------------------------------------------------------------------------------------------ 1x1 GEMM passes of 256 channels
   const lds_u8* const xd_lane = Xd + sep2_a_lane_off(lane);
   const lds_u8* const xr_lane = Un + sep2_a_lane_off(lane);
-  const bool full_out = t0 + TT <= lim;
   int32_t* const pdbg = RES ? p.panes[0].acc_dbg : nullptr;
   const int qlo = f_relu ? max(e.qlo, 0) : e.qlo, qhi = e.qhi;
   // Plain layers with one consumer: the requantisation of one unit (half the frame tiles of a pass; the whole pass at
@@ -638,12 +663,10 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
       const OutP& o0 = e.outs[0];
       const int olo = o0.lo, ohi = o0.hi;
       int8_t* const optr = (int8_t*)o0.ptr;
-      int rl = lim - t0 - 4 * h;
-      asm volatile("" : "+v"(rl));
       v16i accs[2][MH];
       int q4[4];
       unsigned P[4];
-      // accumulator hooks, masked frames, EXACT_Z of a finished unit (tiles mt0 .. mt0 + MH - 1 of pass ps)
+      // accumulator hooks and EXACT_Z of a finished unit (tiles mt0 .. mt0 + MH - 1 of pass ps)
       auto unit_finish = [&](v16i (&a)[MH], int ps, int mt0) __attribute__((always_inline)) {
         const int co = 256 * ps + co_l;
         if (DBG && e.acc_dbg) {
@@ -655,20 +678,8 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
               if (t < eT) e.acc_dbg[((size_t)b * ecout + co) * eTp + t] = a[mt][r];
             }
         }
-        if (!full_out) {
-#pragma unroll
-          for (int mt = 0; mt < MH; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (32 * (mt0 + mt) + (r & 3) + 8 * (r >> 2) >= rl) a[mt][r] = 0;
-        }
         if (f_exact) {
-          unsigned t = 0;
-#pragma unroll
-          for (int mt = 0; mt < MH; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) t |= (unsigned)(a[mt][r] + (1 << 21));
-          if (__any((t >> 22) != 0)) {
+          if (sep2_any_wide<MH>(a)) {
 #pragma unroll
             for (int mt = 0; mt < MH; ++mt)
 #pragma unroll
@@ -686,7 +697,8 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
           if constexpr (r == 15) {
             const auto s02 = __builtin_amdgcn_permlane32_swap(P[0], P[2], false, false);
             const auto s13 = __builtin_amdgcn_permlane32_swap(P[1], P[3], false, false);
-            const v4i pk = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+            v4i pk = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+            if (t0 + 32 * (mt0 + mt + 1) > lim) pk = sep2_mask16(pk, lim - (t0 + 32 * (mt0 + mt) + 16 * h));   // (uniform)
             *(v4i*)(optr + ((size_t)b * ecout + 256 * ps + co_l) * eTp + t0 + 32 * (mt0 + mt) + 16 * h) = pk;
           }
         });
@@ -725,8 +737,6 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
     const v4i* const wnext = more ? w_frag(p.w, CIN_PAD, co + 256, 0) : nullptr;   // this wave's rows in the next pass
     const v4i* const wpane = RES ? w_frag(p.panes[0].w, PCIN_PAD, cor, 0) : nullptr;
     const Sep2PassP& pp = pps[ps];
-    int rl = lim - t0 - 4 * h;                               // frames of this lane's registers below rl are valid;
-    asm volatile("" : "+v"(rl));                             // opaque: keeps 16 MT masks out of the loop-invariant code
     v16i acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -737,8 +747,7 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
     if constexpr (RES) sep2_gemm<MT, NG, (NGP < NG ? NGP : NG)>(acc, wf, xd_lane, CIN_PAD * 32, wpane, wnext);
     else sep2_gemm<MT, NG, 0>(acc, wf, xd_lane, CIN_PAD * 32, nullptr, wnext);
     STAMP2();
-    // accumulator hooks, then masked frames (t >= lim): an accumulator of 0 requantises to 0 for every consumer
-    // (lo <= 0 <= hi) and through res_act
+    // accumulator hooks and EXACT_Z (masked frames t >= lim are zeroed as packed codes in store16)
     auto finish = [&](v16i (&a)[MT], int32_t* dbg, float sb) {
       if (DBG && dbg && co_ok) {
 #pragma unroll
@@ -749,22 +758,10 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
             if (t < eT) dbg[((size_t)b * ecout + co) * eTp + t] = a[mt][r];
           }
       }
-      if (!full_out) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (32 * mt + (r & 3) + 8 * (r >> 2) >= rl) a[mt][r] = 0;
-      }
       if (f_exact) {
         // z == acc is a theorem for |acc| < 2^22; a wave holding an accumulator beyond +-2^21 takes the
         // float32 round trip of fixedpoint_mul (quant_utils.py:187), which is the identity below the bound
-        unsigned t = 0;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) t |= (unsigned)(a[mt][r] + (1 << 21));
-        if (__any((t >> 22) != 0)) {
+        if (sep2_any_wide<MT>(a)) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -781,7 +778,8 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
       for (int g = 0; g < 4; ++g) P[g] = pack4b(q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3]);
       const auto s02 = __builtin_amdgcn_permlane32_swap(P[0], P[2], false, false);
       const auto s13 = __builtin_amdgcn_permlane32_swap(P[1], P[3], false, false);
-      const v4i pk = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+      v4i pk = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+      if (t0 + 32 * (mt + 1) > lim) pk = sep2_mask16(pk, lim - (t0 + 32 * mt + 16 * h));   // masked frames (uniform branch)
       if (co_ok) *(v4i*)((int8_t*)optr + ((size_t)b * ecout + co) * eTp + t0 + 32 * mt + 16 * h) = pk;
     };
 
