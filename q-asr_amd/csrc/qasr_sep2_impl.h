@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
     const int c = cprev + 16 * wave + cb;
 #pragma unroll
     for (int u = 0; u < NU; ++u) acc[u] = (v4i){bias, bias, bias, bias};
-    unsigned tw = 0, P1 = 0, P2 = 0;
+    unsigned tws[2] = {__builtin_amdgcn_alignbyte(in.raw[1], in.raw[0], tsh), 0u}, P1 = 0, P2 = 0;
     double dreg = 0.0;
     int q[4] = {0, 0, 0, 0};
     __builtin_amdgcn_sched_barrier(0);
@@ -510,9 +510,11 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
       if constexpr (u == 0) {
         if constexpr (st == 0) pf3(0);
         if constexpr (st == NS / 2) pf3(1);
-        tw = __builtin_amdgcn_alignbyte(in.raw[st + 1], in.raw[st], tsh);
       }
-      acc[u] = __builtin_amdgcn_mfma_i32_4x4x4i8((int)tw, (int)in.xs[G::OFF + u + st], acc[u], 0, 0, 0);
+      // the next step's tap-stream shift half a step ahead, into the other register: computed where it is used it cost an
+      // s_nop (VALU write -> MFMA read) per step
+      if constexpr (u == NU / 2 && st + 1 < NS) tws[(st + 1) & 1] = __builtin_amdgcn_alignbyte(in.raw[st + 2], in.raw[st + 1], tsh);
+      acc[u] = __builtin_amdgcn_mfma_i32_4x4x4i8((int)tws[st & 1], (int)in.xs[G::OFF + u + st], acc[u], 0, 0, 0);
       sep2_for<OPM * i, OPM * (i + 1)>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       if constexpr (j < NOPS) {
