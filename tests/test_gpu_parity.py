@@ -637,6 +637,40 @@ def test_sep_layer_against_oracle(eng, gen, tile, K, cin, cout, rcin):
             assert np.array_equal(g, want['outs'][j]), (got['label'], T, f'consumer {j}', int((g != want['outs'][j]).sum()))
 
 
+@pytest.mark.parametrize('tile', [32, 64, 128])
+@pytest.mark.parametrize('K,cin,cout,rcin', SEP_SHAPES)
+def test_sep_layer_production_kernels_against_oracle(eng, tile, K, cin, cout, rcin):
+    """The PRODUCTION instantiations of k_sep2 (no accumulator hooks: `DBG = false`, i.e. the pipelined depthwise stage that
+    requantises group g-1 behind group g's MFMAs, and the length masks on packed codes) at operator level: every consumer's
+    output bit-exact against the numpy oracle, with lengths on every edge of the mask logic - full, inside the last 32-frame
+    tile, on a 32- / 16- / 4-frame boundary, one frame, and a tile that lies entirely behind the length."""
+    from qasr.pack import F_EXACT_Z, F_MASK_OUT, F_RELU
+    T = 250
+    rng = np.random.default_rng(K * 77 + cin + rcin + tile)
+    for big in (False, True):
+        c = _sep_case(rng, 8, T, cin, cout, K, True, rcin or None, 2 if rcin else 1, big=big)
+        lens = np.array([250, 249, 224, 208, 131, 100, 17, 1])
+        c['lens'] = lens
+        c['x'] = np.where(np.arange(T)[None, None, :] < lens[:, None, None], c['x'], 0)
+        if c['res'] is not None:
+            c['res']['x'] = np.where(np.arange(T)[None, None, :] < lens[:, None, None], c['res']['x'], 0)
+        want = O.sep_layer_ref(c['x'], c['lens'], c['wdw'], c['m_dw'], (-128, 127), c['wpw'], c['bias'], c['outs'], relu=True,
+                               mask_out=True, sb=c['sb'], exact_z=big, res=c['res'])
+        res = None
+        if c['res'] is not None:
+            res = dict(c['res'], x=torch.from_numpy(c['res']['x'].astype(np.uint8)).cuda())
+        got = eng.sep_layer(torch.from_numpy(c['x'].astype(np.uint8)).cuda(), c['lens'], c['wpw'], c['bias'], c['outs'],
+                            wdw=c['wdw'], m_dw=c['m_dw'], x_unsigned=True, flags=F_RELU | F_MASK_OUT | (F_EXACT_Z if big else 0),
+                            sb=c['sb'], res=res, tile=tile, gen=2, hooks=False)
+        assert got['label'].startswith('k_sep2<') and 'false' in got['label'], got['label']
+        for j, o in enumerate(c['outs']):
+            g = got['outs'][j].cpu().numpy()
+            g = g.view(np.uint8).astype(np.int64) if o['hi'] > 127 else g.astype(np.int64)
+            assert np.array_equal(g, want['outs'][j]), (got['label'], big, f'consumer {j}', int((g != want['outs'][j]).sum()))
+            for b_, n_ in enumerate(lens):
+                assert not g[b_, :, n_:].any(), (got['label'], 'frames behind the length are not zero', b_)
+
+
 def test_sep_layer_dilated_and_bare_1x1(eng):
     """The shapes that stay on k_sep: the dilated depthwise layer of block 16 (K = 87, dilation 2) and a bare 1x1 conv."""
     from qasr.pack import F_MASK_OUT, F_RELU
