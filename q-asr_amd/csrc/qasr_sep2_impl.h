@@ -1,6 +1,6 @@
 // k_sep2: second-generation fused separable-layer kernel (jasper.py:569-600: depthwise conv -> QuantAct -> 1x1 conv
 // [-> residual 1x1 conv + res_act] -> ReLU -> the consumers' QuantAct), stride-1 / dilation-1 depthwise taps.
-// Included by the per-instantiation translation units qasr_sep2_t{32,64}{,_dbg}.hip.
+// Included by the per-instantiation translation units qasr_sep2_t{32,64,128}{,_dbg}.hip.
 //
 // Same decomposition as k_sep (work-group = 512 threads = one utterance x TT frames x every channel; grid (B, Tp/TT)
 // with the utterance as the fastest index so that all tiles of an utterance share one XCD's L2), rebuilt around what
@@ -9,9 +9,15 @@
 //     lo32(fma(f64(z), M, 1.5*2^52)) + v_med3_i32 (3 instructions, exact) replaces the 9-instruction float32 fast path
 //     with its ambiguity vote;
 //   * a CU takes ~50 B/clk from L2 and one work-group asks for ~0.5 MB (256 KiB of 1x1 weights, the window, the taps):
-//     the texture path is the busiest unit, so nothing is fetched twice - the tap rows of a chunk are staged ONCE
-//     through LDS (k_sep: every lane fetched its own pre-shifted copy, 4x the bytes) - and requests are issued in the
+//     the texture path is the busiest unit, so nothing is fetched twice - tap rows go through LDS once
+//     (k_sep: every lane fetched its own pre-shifted copy, 4x the bytes) - and requests are issued in the
 //     order the math needs them (window, taps, then the weight slab);
+//   * the two waves of a SIMD share ONE instruction-issue port and the older wave wins it (profiles/microbench/
+//     coissue.hip): their phases do not overlap, a SIMD's time is the sum of its waves' instructions, and VALU work
+//     hides only behind the SAME wave's MFMAs.  Hence (a) the depthwise stage has no work-group barriers - every wave
+//     stages the window / tap rows of its own 16 channels per group in a private LDS region -, (b) the requantisation
+//     of depthwise group g-1 is issued one instruction behind every 4x4x4 MFMA of group g, (c) per-group constants
+//     are computed once and length masks are applied to packed codes (fewer instructions);
 //   * every global operand is requested >= 1 k cycles before its use: the whole weight slab of the next GEMM sits in
 //     registers (re-requested group by group as soon as a group has been multiplied), per-channel parameters of the
 //     next pass travel during the current one;
