@@ -525,6 +525,17 @@ def run(args):
             result['single_stream_ms_per_step'] = 1e3 * dt1 / args.steps
             result['single_stream_rtfx'] = BATCH * SAMPLES / 16000.0 * args.steps / dt1
             log(f'one step in flight, 32-frame tiles: {1e3 * dt1 / args.steps:.3f} ms/step')
+            # the same layer at the launch geometry of that mode: 256 work-groups, ONE launch fills the chip - the
+            # figure `roofline.frac` (a 64-work-group launch alone on a 256-CU chip) cannot show
+            torch.cuda.synchronize()
+            r1 = dominant_kernel_roofline(lane1['engs'][0], cfg, meta, lane1['engs'][0].time_ops(reps=20).astype(np.float64),
+                                          BATCH, FRAMES // 2)
+            result['roofline']['other']['one_launch_fills_chip'] = {
+                'kernel': r1['kernel'], 'work_groups_per_launch': r1['_wgs'], 'avg_launch_us': r1['avg_launch_us'],
+                'hbm_frac': r1['other']['hbm_frac'], 'mfma_frac': r1['other']['mfma_frac'],
+                'all_ops_ms_per_step_serial': r1['other']['all_ops_ms_per_step_serial'],
+                'timing': 'the one-step-in-flight engine (32-frame tiles), each op replayed 20x between one HIP event pair, '
+                          'nothing else in flight'}
             for e_ in lane1['engs']:
                 e_.close()
         # ---- CPU baseline: the reference's fake-quant op sequence on this host's cores (N=1 only) --------------
