@@ -332,6 +332,7 @@ def run(args):
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the integer engine has no CPU fallback')
     model_name, wbit, abit, BATCH, S_default, baseline_cfg = CONFIGS[args.config]
+    BATCH = int(os.environ.get('QASR_BENCH_BATCH', BATCH))          # (experiments: several batches per launch)
     # QASR_BENCH_BACKEND=gloo rehearses the N>1 control flow on a one-GPU box: every rank uses GPU 0 and the two
     # exchange steps go through host memory.  The measured configuration is always nccl (= RCCL), one GPU per rank.
     backend = os.environ.get('QASR_BENCH_BACKEND', 'nccl')
