@@ -66,6 +66,8 @@ def parse_args(argv=None):
     ap.add_argument('--whole-utterance', action='store_true', help='use the k_utt kernels (one work-group per utterance)')
     ap.add_argument('--streams', type=int, default=int(os.environ.get('QASR_BENCH_STREAMS', 0)),
                     help='independent steps in flight per GPU (each on its own HIP stream + engine arena); 0 = the config default')
+    ap.add_argument('--persistent', type=int, default=int(os.environ.get('QASR_BENCH_PERSISTENT', 0)),
+                    help='1: runs of separable layers as one persistent launch (one work-group per utterance)')
     ap.add_argument('--dry-run', action='store_true',
                     help='rank plumbing only (launcher, process group, blob broadcast, per-step token gather) on synthetic '
                          'payloads: no model, no engine, no GPU needed (gloo when no GPU is visible)')
@@ -95,12 +97,27 @@ def launch_ranks(args, argv):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
-    rcs = [p.wait() for p in procs]
+    # rank 0's JSON line is drained by a thread while EVERY child is polled: the first rank that dies takes the others
+    # with it at once (a survivor would otherwise sit in RCCL initialisation / a collective until its timeout)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.kill()                                 # exactly the children this call started
+                    rcs[i] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = b''.join(chunks).decode()
     if any(rcs):
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
         print(f'bench.py: rank exit codes {rcs}', file=sys.stderr)
         return max(1, max(abs(rc) for rc in rcs))
     sys.stdout.write(out0)
@@ -116,7 +133,10 @@ def pmc_traffic():
     import glob
     import re
     out, src = {}, None
-    fs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_FETCH_SIZE.txt')))
+    def tag(path):                                           # 'r02_v10_...' sorts after 'r02_v9_...': (round, version) as numbers
+        m = re.match(r'r(\d+)_v(\d+)', os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    fs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_FETCH_SIZE.txt')), key=tag)
     if not fs:
         return out, src
     src = os.path.basename(fs[-1]).replace('_pmc_FETCH_SIZE.txt', '')
@@ -378,9 +398,8 @@ def run(args):
     def make_lane(S, tile):
         """S steps in flight: per step in flight an engine (own arena), a HIP stream, its own audio batch and its own
         feature / length / token buffers (stable pointers: the forward replays as one hipGraph launch)."""
-        os.environ['QASR_TILE128'] = '1' if tile == 128 else '0'   # read by qasr_engine_create
-        engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance, wide_tiles=(tile >= 64),
-                              graph=not args.no_graph) for _ in range(S)]
+        engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance, tile=tile, graph=not args.no_graph,
+                              persistent=bool(args.persistent)) for _ in range(S)]      # qasr_engine_opts (include/qasr.h)
         streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
         T_out = engs[0].out_frames(T_pad)
         audio = [torch.from_numpy(synth.make_audio(BATCH, SAMPLES, seed=100 + 16 * rank + k)).to(dev) for k in range(S)]
@@ -490,6 +509,8 @@ def run(args):
                                'decoder + greedy argmax',
                    'global_batch': BATCH * world, 'seq_len': FRAMES, 'weights': 'random-init (qasr.synth, seed 0)',
                    'steps_in_flight': S, 'inputs': 'one audio batch per step in flight (different seeds)',
+                   'log_probs': 'not written in the timed step (tokens and encoded lengths are; the reference forward also returns '
+                                'log-probs: 0.9 MB of stores per step, want_logp=False here)',
                    'hip_graph': not args.no_graph,
                    'kernels': 'k_utt' if args.whole_utterance else f'k_sep2 / k_sep, {tile}-frame tiles' + (' (64 where a layer has residual panes)' if tile == 128 else ''),
                    'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + token gather' if world > 1 else ''),

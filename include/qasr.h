@@ -147,6 +147,38 @@ typedef struct qasr_engine qasr_engine;
 int qasr_engine_create(const void* blob, size_t blob_bytes, int device, int debug, qasr_engine** out);
 void qasr_engine_destroy(qasr_engine* e);
 
+/* The same with every launch-plan choice spelled out (what the `debug` bits and, before round 3, environment variables
+ * selected).  Tri-state fields: -1 = the engine's default, 0 = off, 1 = on.  `struct_size` = sizeof(qasr_engine_opts) of
+ * the caller's header (a shorter, older struct is accepted: missing fields take their defaults; a longer one is refused).
+ * Two engines in one process are configured independently of each other through this call.
+ * Environment variables remain ONLY as A/B overrides for profiling runs of an unmodified caller, read once per create
+ * call AFTER the options: QASR_TILE128=0|1 (128-frame tiles when tile_frames >= 64), QASR_RES_TILE128, QASR_DENSE_TILE128,
+ * QASR_SEP_GEN=1|2, QASR_NO_FUSE, QASR_NO_FUSE_STEM, QASR_NO_FUSE_DEC, QASR_LEGACY_PW, QASR_UTT, QASR_WIDE_TILES,
+ * QASR_PERSISTENT=0|1; QASR_SEP2_TUNE is a kernel-internal experiment knob (csrc/qasr_sep2_impl.h). */
+typedef struct qasr_engine_opts {
+  uint32_t struct_size;
+  uint32_t debug;              /* bit 0: keep every tensor + int32 accumulators (parity hooks); bit 1: one HIP event per op */
+  int32_t tile_frames;         /* frames per work-group of the separable-layer kernels: 0 (= 32), 32, 64 or 128.  32: one
+                                  launch of a 32-utterance batch fills the chip (one step in flight); 128: cheapest frame,
+                                  B * Tp / 128 work-groups per launch (several steps in flight) */
+  int32_t sep_gen;             /* 0 / 2: k_sep2 where it has the shape; 1: round 1's k_sep everywhere */
+  int32_t fuse_dw;             /* depthwise conv fused into the following 1x1 conv's launch */
+  int32_t fuse_stem;           /* block 0 (lengths, first-layer QuantAct, strided depthwise, 1x1) as one launch */
+  int32_t fuse_decoder;        /* decoder conv + log-softmax + argmax + encoded lengths as one launch */
+  int32_t graph;               /* replay the forward as one hipGraph launch (second call with the same buffers captures) */
+  int32_t whole_utterance;     /* k_utt kernels (one work-group per utterance and layer, T <= 256) */
+  int32_t res_tile128;         /* block-end (residual) layers on 128-frame tiles too when tile_frames == 128 */
+  int32_t dense_tile128;       /* Jasper's plain dense convs on 128-frame tiles when tile_frames >= 64 */
+  int32_t legacy_pw;           /* stand-alone 1x1 convs on the v1 kernel k_pw */
+  int32_t persistent;          /* runs of consecutive k_sep2 layers as ONE persistent launch (one work-group per utterance
+                                  walks the layers and both time tiles: no kernel boundary, no inter-work-group exchange);
+                                  meant for many steps in flight - a 32-utterance launch occupies 32 CUs */
+  int32_t reserved[3];
+} qasr_engine_opts;
+/* fills `o` with struct_size and the defaults (-1 / 0) */
+void qasr_engine_default_opts(qasr_engine_opts* o);
+int qasr_engine_create_ex(const void* blob, size_t blob_bytes, int device, const qasr_engine_opts* opts, qasr_engine** out);
+
 /* Encoder + decoder for one batch, replacing ConvASREncoder.forward + ConvASRDecoder.forward + argmax
  * (nemo/collections/asr/modules/conv_asr.py:194-206,270-275; ctc_models.py:403-405).
  * feats   device f32 [B][feat_in][T]   (the preprocessor's output, time contiguous)
@@ -171,6 +203,8 @@ int qasr_engine_num_ops(const qasr_engine* e);
 /* Parity hooks (debug engines only; synchronise the stream).  acc: int32 [B][cout][T_out] = the
  * value rint(conv_int) of QuantConv1d.int_conv (quant_modules.py:304) for op `op` (pane < 0: main conv). */
 int qasr_engine_read_acc(qasr_engine* e, int op, int pane, int32_t* host_out, size_t n_elems);
+/* read_tensor also serves a production (non-debug) engine for a tensor whose arena slot no later tensor reused - e.g.
+ * the decoder's input, the final encoder codes - and refuses the others. */
 int qasr_engine_read_tensor(qasr_engine* e, int tensor, void* host_out, size_t n_bytes, int* T_out, int* Tp_out);
 /* average device time (ms) per op kind over the last forward, measured with HIP events (debug engines) */
 int qasr_engine_last_op_ms(qasr_engine* e, float* ms_per_op, int n_ops);
@@ -318,8 +352,9 @@ int qasr_sep_layer(void* stream, const qasr_sep_layer_args* a, char* label, size
 int qasr_debug_prof(void* dev_buf);
 /* per-work-group timeline of the k_sep2 launches that follow: dev_buf[4 wg .. 4 wg + 3] = {start, end (100 MHz
  * s_memrealtime), HW_ID | XCC_ID << 32, shader cycles (s_memtime) between the two}, wg = blockIdx.y * gridDim.x +
- * blockIdx.x; NULL switches it off */
-int qasr_debug_timeline(void* dev_buf);
+ * blockIdx.x < capacity_work_groups (dev_buf holds 4 * capacity_work_groups int64; work-groups beyond it write nothing);
+ * NULL switches it off.  A forward that would CAPTURE a hipGraph while either diagnostic buffer is set is refused. */
+int qasr_debug_timeline(void* dev_buf, size_t capacity_work_groups);
 
 const char* qasr_last_error(void);
 const char* qasr_version(void);

@@ -133,6 +133,7 @@ class FakeQuantNet:
             xs = xs + [(y, sf)] if (rsites and blk.residual_dense) else [(y, sf)]
         y, sf = xs[-1]
         y, sf = self._act(ai, self.abit, y, sf)
+        enc_codes = torch.round(y / sf).to(torch.int32)          # the decoder QuantAct's integers (conv_asr.py:270)
         logits, _ = self._conv('decoder.decoder_layers.0', None, y, sf, 1, 0, 1, 1)
         logp = torch.log_softmax(logits.transpose(1, 2), dim=-1)
-        return dict(log_probs=logp, tokens=logp.argmax(-1), enc_len=lens, logits=logits)
+        return dict(log_probs=logp, tokens=logp.argmax(-1), enc_len=lens, logits=logits, enc_codes=enc_codes)

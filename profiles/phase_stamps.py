@@ -20,8 +20,6 @@ ap.add_argument('--tile', type=int, default=32, choices=[32, 64, 128])
 ap.add_argument('--gen', type=int, default=2)
 ap.add_argument('--batch', type=int, default=32)
 args = ap.parse_args()
-os.environ['QASR_SEP_GEN'] = str(args.gen)
-os.environ['QASR_TILE128'] = '1' if args.tile == 128 else '0'
 from qasr import engine, pack, synth, topology  # noqa: E402
 
 d = np.load(os.path.join(ROOT, 'tests/golden/net_quartznet_w8a8.npz'))
@@ -29,7 +27,7 @@ meta = json.loads(str(d['meta']))
 cfg = topology.quartznet15x5()
 sd = synth.make_state_dict(cfg, meta['seed'])
 blob, pm = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
-e = engine.Engine(blob, 0, wide_tiles=(args.tile >= 64))
+e = engine.Engine(blob, 0, tile=args.tile, sep_gen=getattr(args, "gen", 2))
 B, T = args.batch, 512
 x = torch.from_numpy(synth.make_features(B, 64, T, 1)).cuda()
 lens = torch.full((B,), 500)

@@ -18,7 +18,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--tile', type=int, default=64)
 ap.add_argument('--batch', type=int, default=32)
 args = ap.parse_args()
-os.environ['QASR_TILE128'] = '1' if args.tile == 128 else '0'
 from qasr import engine, pack, synth, topology  # noqa: E402
 
 d = np.load(os.path.join(ROOT, 'tests/golden/net_quartznet_w8a8.npz'))
@@ -26,7 +25,7 @@ meta = json.loads(str(d['meta']))
 cfg = topology.quartznet15x5()
 sd = synth.make_state_dict(cfg, meta['seed'])
 blob, pm = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
-e = engine.Engine(blob, 0, wide_tiles=(args.tile >= 64))
+e = engine.Engine(blob, 0, tile=args.tile, sep_gen=getattr(args, "gen", 2))
 B, T = args.batch, 512
 x = torch.from_numpy(synth.make_features(B, 64, T, 1)).cuda()
 lens = torch.full((B,), 500)
@@ -42,7 +41,7 @@ for oi, lab in enumerate(labels):
         seen[lab] = oi
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 for lab, oi in seen.items():
-    lib.qasr_debug_timeline(C.c_void_p(0))
+    lib.qasr_debug_timeline(C.c_void_p(0), 0)
     for _ in range(3):
         e.run_op(oi)
     ev[0].record()
@@ -52,7 +51,7 @@ for lab, oi in seen.items():
     torch.cuda.synchronize()
     per_launch = ev[0].elapsed_time(ev[1]) / 20 * 1e3
     buf.zero_()
-    lib.qasr_debug_timeline(C.c_void_p(buf.data_ptr()))
+    lib.qasr_debug_timeline(C.c_void_p(buf.data_ptr()), buf.numel() // 4)
     e.run_op(oi)                                              # previous launch of the same op just ended: warm caches
     e.run_op(oi)
     torch.cuda.synchronize()
@@ -68,5 +67,5 @@ for lab, oi in seen.items():
     print(f'{lab:36s} {len(st):4d} WGs on {slots:3d} (xcc, se, cu) slots | launch {per_launch:6.2f} us (events, back to back) | '
           f'first start -> last end {end.max():6.2f} | starts spread {start.max():5.2f} (p50 {np.median(start):5.2f}) | '
           f'WG duration min {dur.min():5.2f} p50 {np.median(dur):5.2f} max {dur.max():5.2f} | clock {np.median(st[:, 3] / (dur * 1e3)):.2f} GHz')
-lib.qasr_debug_timeline(C.c_void_p(0))
+lib.qasr_debug_timeline(C.c_void_p(0), 0)
 e.close()

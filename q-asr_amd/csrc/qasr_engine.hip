@@ -100,7 +100,9 @@ struct qasr_engine {
   bool fuse_dec = true;                // decoder conv + log-softmax + argmax in one launch (QASR_NO_FUSE_DEC=1: two launches)
   std::vector<char> rq_skip;           // per op: REQUANT op served by the launch of an earlier REQUANT op of the same stored value
   std::vector<char> dec_skip;          // per op: LOGSOFTMAX op that ran inside the preceding decoder launch
-  bool tile128 = true;                 // QASR_TILE128=0: k_sep2's plain layers stay on 64-frame tiles in throughput mode (A/B runs)
+  bool tile128 = true;                 // tile_frames == 128 (QASR_TILE128=0: k_sep2's plain layers stay on 64-frame tiles, A/B runs)
+  bool res_tile128 = true;             // block-end layers on 128-frame tiles too (qasr_engine_opts.res_tile128)
+  bool persistent = false;             // runs of k_sep2 layers as one persistent launch (qasr_engine_opts.persistent)
   bool dense_tile128 = true;           // QASR_DENSE_TILE128=0 keeps Jasper's dense convs on 64-frame tiles (A/B runs)
   bool wide_tiles = false;             // k_sep with 64-frame tiles (throughput mode: bit 3 of `debug`, or QASR_WIDE_TILES=1)
   bool use_utt = false;                // whole-utterance kernels k_utt (bit 2 of `debug`, or QASR_UTT=1)
@@ -112,6 +114,9 @@ struct qasr_engine {
   bool use_graph = false;
   hipGraphExec_t gexec = nullptr;
   const void* gkey[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // everything else the captured front-end nodes bake in: S, n_mels, pad_to, preemph (bits), fb, window (a caller that
+  // reuses its buffers with another S of equal T_pad, or swaps the filterbank, must not replay the old graph)
+  uint64_t gfe[6] = {0, 0, 0, 0, 0, 0};
   int gcalls = 0;                      // forwards seen with the current key (1st: direct launches, 2nd: capture)
 };
 
@@ -340,16 +345,48 @@ const char* qasr_version(void) { return "qasr-hip 0.1 (gfx950)"; }
 int qasr_debug_prof(void* dev_buf) {
   qasr::g_prof = (long long*)dev_buf;
   qasr::g_prof_mode = 0;
+  qasr::g_prof_cap = 0;
   return QASR_OK;
 }
-int qasr_debug_timeline(void* dev_buf) {
+int qasr_debug_timeline(void* dev_buf, size_t capacity_work_groups) {
+  if (dev_buf && (capacity_work_groups < 1 || capacity_work_groups > (1u << 22))) return fail(QASR_ERR_ARG, "debug_timeline: capacity");
   qasr::g_prof = (long long*)dev_buf;
   qasr::g_prof_mode = dev_buf ? 1 : 0;
+  qasr::g_prof_cap = dev_buf ? (int)capacity_work_groups : 0;
   return QASR_OK;
 }
 
+void qasr_engine_default_opts(qasr_engine_opts* o) {
+  if (!o) return;
+  memset(o, 0, sizeof *o);
+  o->struct_size = (uint32_t)sizeof *o;
+  o->fuse_dw = o->fuse_stem = o->fuse_decoder = o->res_tile128 = o->dense_tile128 = -1;
+}
+
+// the `debug` bits of round 1 / 2 callers, as options
 int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_engine** out) {
+  qasr_engine_opts o;
+  qasr_engine_default_opts(&o);
+  o.debug = (uint32_t)debug & 3u;
+  o.whole_utterance = (debug & 4) != 0;
+  o.tile_frames = (debug & 8) ? 128 : 32;
+  o.graph = (debug & 16) != 0;
+  return qasr_engine_create_ex(blob, n, device, &o, out);
+}
+
+int qasr_engine_create_ex(const void* blob, size_t n, int device, const qasr_engine_opts* opts, qasr_engine** out) {
   if (!blob || !out || n < sizeof(qasr_blob_header)) return fail(QASR_ERR_ARG, "null / short blob");
+  qasr_engine_opts o;
+  qasr_engine_default_opts(&o);
+  if (opts) {
+    if (opts->struct_size < 8 || opts->struct_size > sizeof o) return fail(QASR_ERR_ARG, "qasr_engine_opts.struct_size %u (this library: %zu)", opts->struct_size, sizeof o);
+    memcpy(&o, opts, opts->struct_size);                     // an older, shorter struct keeps the defaults of the newer fields
+    o.struct_size = (uint32_t)sizeof o;
+  }
+  if (o.tile_frames != 0 && o.tile_frames != 32 && o.tile_frames != 64 && o.tile_frames != 128)
+    return fail(QASR_ERR_ARG, "qasr_engine_opts.tile_frames %d (0, 32, 64 or 128)", o.tile_frames);
+  if (o.sep_gen < 0 || o.sep_gen > 2) return fail(QASR_ERR_ARG, "qasr_engine_opts.sep_gen %d (0, 1 or 2)", o.sep_gen);
+  const int debug = (int)o.debug;
   qasr_blob_header h;
   memcpy(&h, blob, sizeof h);
   if (h.magic != QASR_BLOB_MAGIC || h.version != QASR_BLOB_VERSION) return fail(QASR_ERR_BLOB, "bad magic / version");
@@ -364,18 +401,32 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
   qasr_engine* e = new qasr_engine();
   e->device = device;
   e->debug = (debug & 1) != 0;
-  e->fuse = getenv("QASR_NO_FUSE") == nullptr;
-  e->legacy_pw = getenv("QASR_LEGACY_PW") != nullptr;
+  e->timing = (debug & 3) != 0;
+  auto tri = [](int32_t v, bool dflt) { return v < 0 ? dflt : v != 0; };
+  e->fuse = tri(o.fuse_dw, true);
+  e->fuse_stem = tri(o.fuse_stem, true);
+  e->fuse_dec = tri(o.fuse_decoder, true);
+  e->legacy_pw = o.legacy_pw > 0;
+  e->wide_tiles = o.tile_frames >= 64;
+  e->tile128 = o.tile_frames == 128;
+  e->res_tile128 = tri(o.res_tile128, true);
+  e->dense_tile128 = tri(o.dense_tile128, true);
+  e->sep_gen = o.sep_gen == 1 ? 1 : 2;
+  e->use_utt = o.whole_utterance > 0;                       // whole-utterance kernels (k_utt) are opt-in (throughput experiments)
+  e->use_graph = o.graph > 0;
+  e->persistent = o.persistent > 0;
+  // environment: A/B overrides for profiling runs of an unmodified caller (include/qasr.h lists them), read per create call
+  if (getenv("QASR_NO_FUSE")) e->fuse = false;
+  if (getenv("QASR_LEGACY_PW")) e->legacy_pw = true;
+  if (getenv("QASR_WIDE_TILES")) { e->wide_tiles = true; e->tile128 = true; }
   if (const char* g = getenv("QASR_TILE128")) e->tile128 = atoi(g) != 0;
+  if (const char* g = getenv("QASR_RES_TILE128")) e->res_tile128 = atoi(g) != 0;
   if (const char* g = getenv("QASR_NO_FUSE_DEC")) e->fuse_dec = atoi(g) == 0;
   if (const char* g = getenv("QASR_NO_FUSE_STEM")) e->fuse_stem = atoi(g) == 0;
   if (const char* g = getenv("QASR_DENSE_TILE128")) e->dense_tile128 = atoi(g) != 0;
   if (const char* g = getenv("QASR_SEP_GEN")) e->sep_gen = atoi(g) == 1 ? 1 : 2;
-  // whole-utterance kernels (k_utt) are opt-in: bit 2 of `debug` or QASR_UTT=1 (throughput experiments)
-  e->use_utt = (debug & 4) != 0 || getenv("QASR_UTT") != nullptr;
-  e->wide_tiles = (debug & 8) != 0 || getenv("QASR_WIDE_TILES") != nullptr;
-  e->use_graph = (debug & 16) != 0;
-  e->timing = (debug & 3) != 0;
+  if (getenv("QASR_UTT")) e->use_utt = true;
+  if (const char* g = getenv("QASR_PERSISTENT")) e->persistent = atoi(g) != 0;
   e->blob.assign((const uint8_t*)blob, (const uint8_t*)blob + n);
   e->h = h;
   e->tdesc = (const qasr_tensor_desc*)(e->blob.data() + h.tensors_off);
@@ -477,7 +528,8 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
   p.cin = (int)op.cin;
   p.cin_pad = rup(p.cin, 128);
   p.n_panes = (int)op.n_panes;
-  p.tile = e->wide_tiles ? (e->tile128 ? 128 : 64) : 32;   // 128: k_sep2's plain layers only (sep2_tile), everything else 64
+  p.tile = e->wide_tiles ? (e->tile128 ? 128 : 64) : 32;   // 128: k_sep2's separable layers only (sep2_tile), everything else 64
+  if (p.tile == 128 && !e->res_tile128 && (op.flags & QASR_F_RESADD)) p.tile = 64;
   p.gen = e->sep_gen;
   fill_panes(e, oi, op, p.panes);
   fill_epi(e, oi, op, p.e);
@@ -777,13 +829,22 @@ static int forward_impl(qasr_engine* e, hipStream_t s, const FrontArgs* fe, floa
   if (e->use_graph && s != nullptr && !e->timing && !e->debug) {   // the legacy default stream cannot be captured
     const void* key[8] = {feats, lens, logp, tokens, lens_out, fe ? fe->audio : nullptr, fe ? fe->audio_lens : nullptr,
                           fe ? fe->plan : nullptr};
+    uint64_t fkey[6] = {0, 0, 0, 0, 0, 0};
+    if (fe) {
+      uint32_t pre_bits;
+      memcpy(&pre_bits, &fe->preemph, 4);
+      fkey[0] = (uint64_t)fe->S; fkey[1] = (uint64_t)fe->n_mels; fkey[2] = (uint64_t)fe->pad_to; fkey[3] = pre_bits;
+      fkey[4] = (uint64_t)(uintptr_t)fe->fb; fkey[5] = (uint64_t)(uintptr_t)fe->window;
+    }
     bool same = true;
     for (int i = 0; i < 8; ++i) same = same && key[i] == e->gkey[i];
-    if (!same) {                                             // new buffer set: drop the old graph, start over
+    for (int i = 0; i < 6; ++i) same = same && fkey[i] == e->gfe[i];
+    if (!same) {                                             // new buffer set / front-end arguments: drop the old graph, start over
       if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
       e->gexec = nullptr;
       e->gcalls = 0;
       for (int i = 0; i < 8; ++i) e->gkey[i] = key[i];
+      for (int i = 0; i < 6; ++i) e->gfe[i] = fkey[i];
     }
     if (e->gexec) {
       HIPCHK(hipGraphLaunch(e->gexec, s));
@@ -791,10 +852,15 @@ static int forward_impl(qasr_engine* e, hipStream_t s, const FrontArgs* fe, floa
     }
     if (e->gcalls++ >= 1) {                                  // second call with this key: capture (the first one ran every
       hipGraph_t g = nullptr;                                // kernel's one-time attribute setup outside a capture)
+      if (g_prof) return fail(QASR_ERR_ARG, "graph capture while qasr_debug_prof / qasr_debug_timeline is set: the buffer would be baked into the graph");
       HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       int rc = enqueue();
       hipError_t ce = hipStreamEndCapture(s, &g);
-      if (rc) return rc;
+      if (rc) {                                              // an enqueue error inside the capture: nothing is kept
+        if (g) (void)hipGraphDestroy(g);
+        e->gcalls = 0;
+        return rc;
+      }
       if (ce != hipSuccess || !g) return fail(QASR_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
       hipError_t ie = hipGraphInstantiate(&e->gexec, g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
@@ -921,8 +987,13 @@ int qasr_engine_read_acc(qasr_engine* e, int op, int pane, int32_t* host_out, si
 }
 
 int qasr_engine_read_tensor(qasr_engine* e, int tensor, void* host_out, size_t n_bytes, int* T_out, int* Tp_out) {
-  if (!e || !e->debug || tensor <= 0 || tensor >= (int)e->tens.size()) return fail(QASR_ERR_ARG, "read_tensor: bad tensor / not debug");
+  if (!e || tensor <= 0 || tensor >= (int)e->tens.size()) return fail(QASR_ERR_ARG, "read_tensor: bad tensor / no forward yet");
   const TensorRT& t = e->tens[tensor];
+  if (!e->debug) {                                           // production engines reuse arena slots: only a tensor nobody overwrote
+    for (size_t i = 1; i < e->tens.size(); ++i)
+      if ((int)i != tensor && e->tens[i].slot == t.slot && e->tens[i].d.producer > t.d.producer)
+        return fail(QASR_ERR_ARG, "read_tensor: the arena slot of tensor %d was reused by tensor %zu (debug engines keep every tensor)", tensor, i);
+  }
   if (T_out) *T_out = t.T;
   if (Tp_out) *Tp_out = t.Tp;
   size_t want = (t.d.dtype == QASR_DT_F32) ? (size_t)e->B * t.T * t.d.channels * 4 : (size_t)e->B * t.d.channels * t.Tp * dt_size(t.d.dtype);

@@ -88,12 +88,14 @@ struct SepP {             // fused separable layer: depthwise stencil -> QuantAc
   const int32_t* r32;     // k_utt EP_ADD32: res_act operand rint(acc_res * M_res) of the block's residual conv
   long long* prof;        // diagnostics: s_memtime stamps of work-group (0,0,0), wave 0 (qasr_debug_prof)
   int prof_mode;          // 1 (qasr_debug_timeline): every work-group writes {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, shader cycles}
+  int prof_cap;           // ... for work-groups below this count (the caller's buffer)
   PaneP panes[QASR_MAX_PANES];
   EpiP e;
 };
 
 extern long long* g_prof;
 extern int g_prof_mode;
+extern int g_prof_cap;      // timeline mode: work-groups the buffer holds (4 int64 each)
 
 struct QuantInP {
   const float* x;         // [B][C][T]

@@ -7,6 +7,7 @@ namespace qasr {
 
 long long* g_prof = nullptr;
 int g_prof_mode = 0;
+int g_prof_cap = 0;
 
 extern template int launch_sep_inst<32, false>(hipStream_t, const SepP&);
 extern template int launch_sep_inst<32, true>(hipStream_t, const SepP&);
@@ -24,12 +25,10 @@ bool sep2_takes(const SepP& p) { return p.gen == 2 && sep2_shape_ok(p); }
 // frames per work-group of a k_sep2 launch: 128 for the depthwise-separable layers when the engine asks for it
 // (throughput mode: every weight fragment then feeds four frame tiles, B * Tp / 128 work-groups per launch), else the
 // engine's 32 / 64.  The block-end (residual) layers too: with the decoder and the stem fused it is 0.417 vs 0.424 ms per step
-// and steadier (four 64-work-group launches fit the chip side by side, four 128-work-group ones queue); QASR_RES_TILE128=0
-// keeps them on 64 (A/B runs)
+// and steadier (four 64-work-group launches fit the chip side by side, four 128-work-group ones queue);
+// qasr_engine_opts.res_tile128 = 0 keeps them on 64 (the engine then hands those ops over with tile = 64)
 static int sep2_tile(const SepP& p) {
-  static const bool res128 = [] { const char* g = getenv("QASR_RES_TILE128"); return !g || atoi(g) != 0; }();
-  if (p.tile == 128)
-    return (p.K > 0 && p.e.Tp % 128 == 0 && (res128 || !(p.e.flags & QASR_F_RESADD))) ? 128 : 64;
+  if (p.tile == 128) return (p.K > 0 && p.e.Tp % 128 == 0) ? 128 : 64;
   return p.tile == 64 ? 64 : 32;
 }
 

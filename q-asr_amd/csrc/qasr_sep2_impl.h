@@ -848,7 +848,7 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   }
   }
   if (stamp) p.prof[31] = nst;
-  if (tline) {
+  if (tline && (int)(blockIdx.y * gridDim.x + blockIdx.x) < p.prof_cap) {
     long long* r = p.prof + 4 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
     r[0] = tl_start;
     r[1] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -913,6 +913,7 @@ static int launch_sep2_v(hipStream_t s, const SepP& p) {
   q.prof = g_prof;
   static const int tune = getenv("QASR_SEP2_TUNE") ? atoi(getenv("QASR_SEP2_TUNE")) : 0;
   q.prof_mode = g_prof_mode | (tune << 8);
+  q.prof_cap = g_prof_cap;
   hipLaunchKernelGGL((k_sep2<K, NG, NGP, NP, DBG, TT>), dim3(p.e.B, p.e.Tp / TT, 1), dim3(SEP2_NT), smem, s, q);
   return QASR_OK;
 }

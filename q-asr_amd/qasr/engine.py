@@ -9,7 +9,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('QASR_LIB', os.path.join(HERE, 'libqasr_hip.so'))   # QASR_LIB: A/B builds in one run
 
-SYMBOLS = ['qasr_engine_create', 'qasr_engine_destroy', 'qasr_engine_forward', 'qasr_engine_forward_audio', 'qasr_engine_out_frames',
+SYMBOLS = ['qasr_engine_create', 'qasr_engine_create_ex', 'qasr_engine_default_opts', 'qasr_engine_destroy', 'qasr_engine_forward', 'qasr_engine_forward_audio', 'qasr_engine_out_frames',
            'qasr_engine_num_ops', 'qasr_engine_read_acc', 'qasr_engine_read_tensor', 'qasr_engine_last_op_ms',
            'qasr_engine_time_ops', 'qasr_engine_run_op', 'qasr_engine_op_label',
            'qasr_frontend_mel', 'qasr_frontend_plan', 'qasr_frontend_mel_planned', 'qasr_frontend_frames',
@@ -38,6 +38,14 @@ class SepLayerArgs(C.Structure):
                 [('outs', _SepOut * 3), ('dw_acc', C.c_void_p), ('acc', C.c_void_p), ('racc', C.c_void_p)])
 
 
+class EngineOpts(C.Structure):
+    """qasr_engine_opts (include/qasr.h): the launch-plan choices of one engine."""
+    _fields_ = ([('struct_size', C.c_uint32), ('debug', C.c_uint32)] +
+                [(n, C.c_int32) for n in ('tile_frames', 'sep_gen', 'fuse_dw', 'fuse_stem', 'fuse_decoder', 'graph',
+                                          'whole_utterance', 'res_tile128', 'dense_tile128', 'legacy_pw', 'persistent')] +
+                [('reserved', C.c_int32 * 3)])
+
+
 class QasrError(RuntimeError):
     pass
 
@@ -53,6 +61,9 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
     lib.qasr_engine_create.argtypes = [vp, sz, i32, i32, C.POINTER(vp)]
+    lib.qasr_engine_create_ex.argtypes = [vp, sz, i32, C.POINTER(EngineOpts), C.POINTER(vp)]
+    lib.qasr_engine_default_opts.argtypes = [C.POINTER(EngineOpts)]
+    lib.qasr_engine_default_opts.restype = None
     lib.qasr_engine_destroy.argtypes = [vp]
     lib.qasr_engine_destroy.restype = None
     lib.qasr_engine_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
@@ -81,7 +92,7 @@ def load_library():
     lib.qasr_dyn_quant_in.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.qasr_dyn_conv_params.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.qasr_debug_prof.argtypes = [vp]
-    lib.qasr_debug_timeline.argtypes = [vp]
+    lib.qasr_debug_timeline.argtypes = [vp, sz]
     lib.qasr_sep_layer.argtypes = [vp, C.POINTER(SepLayerArgs), C.c_char_p, sz]
     lib.qasr_quantile2.argtypes = [vp, vp, sz, C.c_float, C.c_float, vp, vp, sz]
     lib.qasr_quantile_workspace_bytes.argtypes = []
@@ -110,7 +121,10 @@ class Engine:
     """One packed model on one GPU (qasr_engine_*)."""
 
     def __init__(self, blob: bytes, device=0, debug=False, timing=False, whole_utterance=False, wide_tiles=False,
-                 graph=False):
+                 graph=False, tile=None, sep_gen=None, fuse_dw=None, fuse_stem=None, fuse_decoder=None, res_tile128=None,
+                 dense_tile128=None, persistent=False):
+        """Options = qasr_engine_opts (include/qasr.h).  tile: frames per work-group (32 / 64 / 128; `wide_tiles=True` is the
+        older spelling of 128); None leaves a choice at the engine's default."""
         lib = load_library()
         if not torch.cuda.is_available():
             raise QasrError('no GPU: the integer engine needs an MI355X (there is no CPU fallback)')
@@ -119,9 +133,20 @@ class Engine:
         self._blob = blob
         self._h = C.c_void_p()
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
-        _check(lib.qasr_engine_create(C.cast(buf, C.c_void_p), len(blob), device, int(bool(debug)) | (2 if timing else 0) | (4 if whole_utterance else 0) | (8 if wide_tiles else 0) | (16 if graph else 0),
-                                      C.byref(self._h)),
-               'qasr_engine_create')
+        o = EngineOpts()
+        lib.qasr_engine_default_opts(C.byref(o))
+        assert o.struct_size == C.sizeof(EngineOpts), 'qasr_engine_opts: header and binding disagree'
+        o.debug = int(bool(debug)) | (2 if timing else 0)
+        o.tile_frames = int(tile) if tile else (128 if wide_tiles else 32)
+        o.sep_gen = int(sep_gen or 0)
+        for name, v in (('fuse_dw', fuse_dw), ('fuse_stem', fuse_stem), ('fuse_decoder', fuse_decoder),
+                        ('res_tile128', res_tile128), ('dense_tile128', dense_tile128)):
+            if v is not None:
+                setattr(o, name, int(bool(v)))
+        o.graph, o.whole_utterance, o.persistent = int(bool(graph)), int(bool(whole_utterance)), int(bool(persistent))
+        self.opts = o
+        _check(lib.qasr_engine_create_ex(C.cast(buf, C.c_void_p), len(blob), device, C.byref(o), C.byref(self._h)),
+               'qasr_engine_create_ex')
         self.debug = debug
         self.n_ops = lib.qasr_engine_num_ops(self._h)
         hdr = np.frombuffer(blob[:40], dtype=np.uint32)

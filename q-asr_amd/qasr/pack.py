@@ -477,7 +477,10 @@ class Packer:
         blob = self.serialise()
         meta = dict(sites=self.sites, n_ops=len(self.final_ops), n_tensors=len(self.tensors),
                     kinds=[o['kind'] for o in self.final_ops],
-                    tensors=[dict(t) for t in self.tensors], domains=[dict(d) for d in self.domains])
+                    tensors=[dict(t) for t in self.tensors], domains=[dict(d) for d in self.domains],
+                    # the decoder's input: the final encoder codes (block 17's output behind the decoder's QuantAct)
+                    dec_in=next((o['in_tensor'] if 'in_tensor' in o else o['inp'].tensor)
+                                for o in self.final_ops if o['kind'] == OP_PW and o['flags'] & F_LOGITS))
         return blob, meta
 
 

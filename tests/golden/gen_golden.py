@@ -46,7 +46,7 @@ _torch_sqrt = torch.sqrt
 
 
 def _ieee_sqrt(x, *a, **k):
-    if isinstance(x, torch.Tensor) and x.dtype == torch.float32 and not a and not k:
+    if isinstance(x, torch.Tensor) and x.dtype == torch.float32 and not a and not k and not x.requires_grad:   # (autograd: gen_distill)
         return torch.from_numpy(np.sqrt(x.detach().numpy().astype(np.float64)).astype(np.float32))
     return _torch_sqrt(x, *a, **k)
 
@@ -96,7 +96,7 @@ class ConvTap:
         ref_qmod.F.conv1d = self._orig
 
 
-def build_reference_model(cfg, sd, wbit, abit, percentile):
+def build_reference_model(cfg, sd, wbit, abit, percentile, fold=True):
     """Restates the 40-line assembly loop of ConvASREncoder.__init__ (conv_asr.py:136-192)
     and ConvASRDecoder.__init__ (:247-268) around the reference's own JasperBlock /
     QuantAct / QuantConv1d, then loads the synthetic checkpoint by its NeMo keys."""
@@ -149,8 +149,9 @@ def build_reference_model(cfg, sd, wbit, abit, percentile):
     model.decoder.decoder_layers[0].weight_bit = wbit
     if percentile is not None:
         qm.set_percentile(model, percentile)
-    for blk in blocks:
-        blk.bn_folding()
+    if fold:
+        for blk in blocks:
+            blk.bn_folding()
     return model, blocks
 
 
@@ -401,6 +402,71 @@ def gen_frontend():
     print('frontend.npz:', tuple(y.shape), seq.tolist())
 
 
+def gen_distill():
+    """Zero-shot calibration data: the reference's OWN nemo/quantization/utils/distill_data.py
+    (get_synthetic_data, _kl_loss; imported unmodified) on a float ('none' mode, BatchNorm not folded) MiniQuartzNet built
+    from the reference's JasperBlocks.  Its random start (_get_random_data: 32 loader workers drawing uniform noise) is
+    replaced by a fixed seeded tensor; 3 Adam iterations on 2 batches.  Stored: the start, every _kl_loss call's inputs'
+    result, the loss of every iteration, the refined batches, and stand-alone _kl_loss known answers."""
+    import nemo.quantization.utils.distill_data as ref_dd
+    cfg = topology.MODELS['MiniQuartzNet']()
+    seed, B, T, iters, nb, lr = 3, 2, 48, 3, 2, 0.05
+    sd = synth.make_state_dict(cfg, seed)
+    model, blocks = build_reference_model(cfg, sd, 8, 8, None, fold=False)
+    for blk in blocks:
+        blk.set_quant_mode('none')
+    model.decoder.act.quant_mode = 'none'
+    model.decoder.decoder_layers[0].quant_mode = 'none'
+
+    class Teacher(nn.Module):                                  # ConvASREncoder's forward + convs_before_bn (conv_asr.py:134,185,194-206)
+        def __init__(self):
+            super().__init__()
+            self.encoder = nn.Sequential(*blocks)
+            self.convs_before_bn = [cb for blk in blocks for cb in blk.convs_before_bn]
+
+        def forward(self, x, length):
+            return encoder_forward(blocks, x, length)
+
+    class TeacherDecoder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dec = model.decoder
+
+        def forward(self, encoder_output, encoder_output_scaling_factor=None):
+            return decoder_forward(self.dec, encoder_output, encoder_output_scaling_factor)[1]
+
+    g = torch.Generator().manual_seed(1234)
+    start = [torch.rand(B, cfg.feat_in, T, generator=g) * 0.6 - 0.3 for _ in range(nb)]
+    ref_dd._get_random_data = lambda batch_size, dim, seqlen: [t.clone() for t in start]
+    ref_dd.tqdm = lambda it: it
+    kl_calls = []
+    kl_orig = ref_dd._kl_loss
+
+    def kl_rec(*a):
+        v = kl_orig(*a)
+        kl_calls.append(float(v))
+        return v
+    ref_dd._kl_loss = kl_rec
+    # ReduceLROnPlateau(verbose=True) is rejected by torch 2.10: same scheduler without the keyword
+    rl_orig = ref_dd.optim.lr_scheduler.ReduceLROnPlateau
+    ref_dd.optim.lr_scheduler.ReduceLROnPlateau = lambda opt, **kw: rl_orig(opt, **{k: v for k, v in kw.items() if k != 'verbose'})
+    with torch.enable_grad():
+        out = ref_dd.get_synthetic_data(Teacher(), TeacherDecoder(), batch_size=B, dim=cfg.feat_in, seqlen=T, train_iter=iters,
+                                        num_batch=nb, lr=lr)
+    ref_dd.optim.lr_scheduler.ReduceLROnPlateau = rl_orig
+    n_hooks = len(kl_calls) // (iters * nb)
+    losses = np.array(kl_calls, np.float64).reshape(nb * iters, n_hooks).sum(1)
+    one = torch.ones(5)
+    kl_known = np.array([float(kl_orig(one * 0.3, one * 2, one * 0.3, one * 2)), float(kl_orig(one * 0.3, one * 2, one * 0.5, one * 1.5)),
+                         float(kl_orig(torch.tensor([0.1, -0.2]), torch.tensor([1.0, 0.5]), torch.tensor([0.0, 0.3]), torch.tensor([2.0, 0.25])))])
+    np.savez_compressed(os.path.join(HERE, 'distill.npz'), start=np.stack([t.numpy() for t in start]),
+                        refined=np.stack([t.numpy() for t in out]), kl_calls=np.array(kl_calls, np.float64), losses=losses,
+                        kl_known=kl_known,
+                        meta=json.dumps(dict(model='MiniQuartzNet', seed=seed, batch=B, frames=T, train_iter=iters, num_batch=nb,
+                                             lr=lr, n_hooks=n_hooks)))
+    print('distill.npz:', losses.round(4).tolist(), 'max |refined - start| =', float(np.abs(np.stack([t.numpy() for t in out]) - np.stack([t.numpy() for t in start])).max()))
+
+
 def gen_wer():
     """Known answers quoted from /root/reference/tests/collections/asr/test_asr_metrics.py:94-111."""
     cases = [dict(hyp=['cat'], ref=['cot'], wer=1.0),
@@ -420,6 +486,8 @@ if __name__ == '__main__':
         gen_wer()
     if not which or 'frontend' in which:
         gen_frontend()
+    if not which or 'distill' in which:
+        gen_distill()
     M = topology.MODELS
     if not which or 'mini' in which:
         run_net('net_miniq_w8a8', M['MiniQuartzNet'](), 1, 8, 8, None, 3, 96, (96, 71, 40), 3, 4, True)

@@ -33,10 +33,11 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_packer(tmp_path):
     probe = tmp_path / 'probe.c'
-    probe.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "qasr.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    probe.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "qasr.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                      'sizeof(qasr_blob_header),sizeof(qasr_tensor_desc),sizeof(qasr_op_desc),sizeof(qasr_out),'
                      'sizeof(qasr_pane),sizeof(qasr_domain_desc),sizeof(qasr_sep_layer_args),'
-                     'offsetof(qasr_sep_layer_args, outs),offsetof(qasr_sep_layer_args, racc));return 0;}\n')
+                     'offsetof(qasr_sep_layer_args, outs),offsetof(qasr_sep_layer_args, racc),'
+                     'sizeof(qasr_engine_opts),offsetof(qasr_engine_opts, tile_frames),offsetof(qasr_engine_opts, persistent));return 0;}\n')
     exe = tmp_path / 'probe'
     subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(probe), '-o', str(exe)], check=True)
     sizes = list(map(int, subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()))
@@ -48,6 +49,29 @@ def test_struct_sizes_match_packer(tmp_path):
     from qasr import engine                                   # the ctypes mirror of the operator-level argument block
     assert sizes[6] == ctypes.sizeof(engine.SepLayerArgs)
     assert sizes[7] == engine.SepLayerArgs.outs.offset and sizes[8] == engine.SepLayerArgs.racc.offset
+    assert sizes[9] == ctypes.sizeof(engine.EngineOpts) == 64      # the engine's launch-plan options (qasr_engine_create_ex)
+    assert sizes[10] == engine.EngineOpts.tile_frames.offset and sizes[11] == engine.EngineOpts.persistent.offset
+
+
+def test_engine_opts_defaults_and_validation():
+    """qasr_engine_default_opts fills the struct; create_ex validates the options before any HIP call."""
+    from qasr import build, engine
+    lib = ctypes.CDLL(build.build_native())
+    lib.qasr_last_error.restype = ctypes.c_char_p
+    o = engine.EngineOpts()
+    lib.qasr_engine_default_opts(ctypes.byref(o))
+    assert o.struct_size == ctypes.sizeof(engine.EngineOpts) and o.tile_frames == 0 and o.sep_gen == 0 and o.persistent == 0
+    assert (o.fuse_dw, o.fuse_stem, o.fuse_decoder, o.res_tile128, o.dense_tile128) == (-1,) * 5 and o.graph == 0
+    h = ctypes.c_void_p()
+    blob = ctypes.create_string_buffer(256)
+    lib.qasr_engine_create_ex.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    o.tile_frames = 48
+    assert lib.qasr_engine_create_ex(blob, 256, 0, ctypes.byref(o), ctypes.byref(h)) == 1 and b'tile_frames' in lib.qasr_last_error()
+    o.tile_frames, o.struct_size = 128, 4096
+    assert lib.qasr_engine_create_ex(blob, 256, 0, ctypes.byref(o), ctypes.byref(h)) == 1 and b'struct_size' in lib.qasr_last_error()
+    o.struct_size = 16                                         # an older, shorter struct is accepted (then the blob is checked)
+    assert lib.qasr_engine_create_ex(blob, 256, 0, ctypes.byref(o), ctypes.byref(h)) == 2 and b'magic' in lib.qasr_last_error()
+    assert lib.qasr_engine_create_ex(blob, 256, 0, None, ctypes.byref(h)) == 2      # NULL options = defaults
 
 
 def test_engine_create_rejects_garbage_without_touching_gpu():

@@ -290,6 +290,36 @@ def test_en_char_parser_normalisation():
     assert base("A-b") == [vocab.index('a'), vocab.index('b')]          # unknown '-' -> unk_id == blank_id -> dropped
 
 
+def test_distill_matches_reference_fixture(golden_dir):
+    """tests/golden/distill.npz = the reference's own distill_data.get_synthetic_data / _kl_loss (imported unmodified by
+    gen_golden.py) on a float MiniQuartzNet: 3 Adam iterations on 2 fixed start batches.  This repo's get_synthetic_data
+    from the same start must give the same per-iteration losses and the same refined batches (rtol 1e-5), _kl_loss the
+    same known answers."""
+    import json
+
+    from nemo.quantization.utils import distill_data
+    d = np.load(os.path.join(golden_dir, 'distill.npz'))
+    meta = json.loads(str(d['meta']))
+    m = EncDecCTCModel.from_synthetic(meta['model'], seed=meta['seed'])
+    m.set_quant_mode('none')
+    assert len(m.encoder.convs_before_bn) == meta['n_hooks']
+    hist = []
+    out = distill_data.get_synthetic_data(m.encoder, m.decoder, batch_size=meta['batch'], dim=d['start'].shape[2], seqlen=meta['frames'],
+                                          train_iter=meta['train_iter'], num_batch=meta['num_batch'], lr=meta['lr'], verbose=False,
+                                          history=hist, init=[torch.from_numpy(t) for t in d['start']])
+    np.testing.assert_allclose(np.array(hist), d['losses'], rtol=1e-5)
+    assert d['losses'][2] < d['losses'][0] and d['losses'][5] < d['losses'][3]
+    got = np.stack([t.numpy() for t in out])
+    assert np.abs(d['refined'] - d['start']).max() > 0.1          # the optimiser moved the data ...
+    np.testing.assert_allclose(got, d['refined'], rtol=1e-5, atol=1e-6)   # ... to where the reference moved it
+    one = torch.ones(5)
+    kl = [float(distill_data._kl_loss(one * 0.3, one * 2, one * 0.3, one * 2)), float(distill_data._kl_loss(one * 0.3, one * 2, one * 0.5, one * 1.5)),
+          float(distill_data._kl_loss(torch.tensor([0.1, -0.2]), torch.tensor([1.0, 0.5]), torch.tensor([0.0, 0.3]), torch.tensor([2.0, 0.25])))]
+    np.testing.assert_allclose(kl, d['kl_known'], rtol=1e-6, atol=1e-7)
+    assert all(p.requires_grad for p in m.encoder.parameters())   # the weights' requires_grad is restored
+    assert all(len(c._forward_hooks) == 0 for c, _ in m.encoder.convs_before_bn)
+
+
 def test_synthesize_zero_shot_calibration_data(tmp_path):
     """synthesize.py / distill_data.get_synthetic_data (distill_data.py:71-162): the BN-statistics loss of the float mini
     model goes down under Adam on the input, and the dumped pickle is what `inference.py --load` reads."""
@@ -306,7 +336,6 @@ def test_synthesize_zero_shot_calibration_data(tmp_path):
                                           lr=0.05, seed=1, verbose=False, history=hist)
     assert len(out) == 2 and out[0].shape == (2, 16, 48) and not out[0].requires_grad
     assert hist[11] < hist[0] and hist[23] < hist[12], hist      # the loss of each batch decreases
-    assert not torch.is_grad_enabled() or True
     assert len(m.encoder.convs_before_bn) > 0 and all(len(c._forward_hooks) == 0 for c, _ in m.encoder.convs_before_bn)
     # _kl_loss is 0 for identical Gaussians and positive otherwise
     one = torch.ones(4)

@@ -202,3 +202,66 @@ def test_forward_audio_equals_frontend_plus_forward(golden_dir):
         assert torch.equal(lp, lp0) and torch.equal(tk, tk0) and torch.equal(el, el0), call
     e1.close()
     e2.close()
+
+
+def test_graph_key_covers_frontend_arguments(golden_dir):
+    """the captured front-end nodes bake in S, the filterbank and the window.  Two sample counts with the same
+    padded frame count (40000 and 39840 samples -> 251 / 250 frames -> T_pad 256) through the SAME buffers, and a swapped
+    filterbank pointer, must not replay the old graph: every call equals the kernel-by-kernel engine."""
+    from qasr import engine, melbank, pack
+    d = np.load(os.path.join(golden_dir, 'net_quartznet_w8a8.npz'))
+    meta = json.loads(str(d['meta']))
+    cfg = topology.quartznet15x5()
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    blob, _ = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    fb = torch.from_numpy(melbank.mel_filterbank(16000, 512, 64, 0.0, 8000.0).astype(np.float32)).cuda().contiguous()
+    fb2 = (fb * 0.5).contiguous()                              # another filterbank (own tables, own pointer)
+    win = torch.hann_window(320, periodic=False).cuda()
+    plan, plan2 = engine.frontend_plan(fb), engine.frontend_plan(fb2)
+    B = 3
+    base = torch.empty(B * 40000, device='cuda')
+    g, ref = engine.Engine(blob, 0, graph=True), engine.Engine(blob, 0)
+    T_pad = g.lib.qasr_frontend_frames(40000, 16)
+    assert T_pad == g.lib.qasr_frontend_frames(39840, 16) == 256
+    To = g.out_frames(T_pad)
+    fbuf = torch.empty(B, 64, T_pad, device='cuda')
+    lbuf = torch.empty(B, dtype=torch.int32, device='cuda')
+    out = (torch.empty(B, To, 29, device='cuda'), torch.empty(B, To, dtype=torch.int32, device='cuda'),
+           torch.empty(B, dtype=torch.int32, device='cuda'))
+    st = torch.cuda.Stream()
+    calls = [(40000, fb, plan)] * 3 + [(39840, fb, plan)] * 3 + [(39840, fb2, plan2)] * 3 + [(40000, fb, plan)] * 2
+    for ci, (S, f, pl) in enumerate(calls):
+        audio = base[:B * S].view(B, S)
+        audio.copy_(torch.from_numpy(synth.make_audio(B, S, seed=50 + S % 7)))
+        alen = torch.tensor([S, S - 4000, S - 9000], dtype=torch.int32).cuda()
+        torch.cuda.synchronize()
+        lp0, tk0, el0 = ref.forward_audio(audio, alen, f, win, pl, 0.97, 16)
+        for t in out:
+            t.zero_()
+        with torch.cuda.stream(st):
+            lp, tk, el = g.forward_audio(audio, alen, f, win, pl, 0.97, 16, feats=fbuf, feat_lens=lbuf, out=out)
+        torch.cuda.synchronize()
+        assert torch.equal(tk, tk0) and torch.equal(el, el0) and torch.equal(lp, lp0), (ci, S)
+    g.close()
+    ref.close()
+
+
+def test_distill_on_gpu_matches_reference_fixture(golden_dir):
+    """SURVEY 8f-3 on PyTorch-ROCm: get_synthetic_data with the model on the GPU against tests/golden/distill.npz (the
+    reference's own module on the CPU, 3 Adam iterations from a fixed start).  Tolerance: MIOpen's float32 conv / reduction
+    order differs from the CPU's - losses rtol 1e-3, refined batches atol 2e-3 (the data moves by up to 0.15; Adam's first
+    steps are sign-like, so a step flips only where a gradient is within rounding of zero)."""
+    from nemo.collections.asr.models import EncDecCTCModel
+    from nemo.quantization.utils import distill_data
+    d = np.load(os.path.join(golden_dir, 'distill.npz'))
+    meta = json.loads(str(d['meta']))
+    m = EncDecCTCModel.from_synthetic(meta['model'], seed=meta['seed']).cuda()
+    m.set_quant_mode('none')
+    hist = []
+    out = distill_data.get_synthetic_data(m.encoder, m.decoder, batch_size=meta['batch'], dim=d['start'].shape[2], seqlen=meta['frames'],
+                                          train_iter=meta['train_iter'], num_batch=meta['num_batch'], lr=meta['lr'], verbose=False,
+                                          history=hist, init=[torch.from_numpy(t) for t in d['start']])
+    assert all(t.is_cuda for t in out)
+    np.testing.assert_allclose(np.array(hist), d['losses'], rtol=1e-3)
+    got = np.stack([t.cpu().numpy() for t in out])
+    assert np.mean(np.abs(got - d['refined']) <= 2e-3) > 0.999, float(np.abs(got - d['refined']).max())

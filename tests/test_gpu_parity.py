@@ -107,8 +107,11 @@ def test_requant_exact_z_golden(eng, golden_dir):
     acc = torch.from_numpy(d['requant_big_acc']).cuda()
     got = eng.requant(acc, M, -128, 127, sb=torch.from_numpy(pre), exact_z=True).cpu().numpy()
     assert np.array_equal(got, d['requant_big_q'])
-    fast = eng.requant(acc, M, -128, 127).cpu().numpy()       # the shortcut is NOT valid here (documented bound)
-    assert (fast != d['requant_big_q']).sum() >= 0
+    # without QASR_F_EXACT_Z the kernel requantises the accumulator itself: clamp(rint(f64(acc) * M)) - which is NOT
+    # fixedpoint_mul's result beyond 2^22 (the packer sets the flag there); pinned here against numpy
+    fast = eng.requant(acc, M, -128, 127).cpu().numpy()
+    want_fast = np.clip(np.rint(d['requant_big_acc'].astype(np.float64) * M.numpy().reshape(1, -1, 1)), -128, 127)
+    assert np.array_equal(fast, want_fast.astype(np.int8))
 
 
 # ---------------------------------------------------------------------------------- networks
@@ -207,6 +210,16 @@ def test_bench_size_properties(eng, golden_dir):
     n = int(el4[0])
     assert np.array_equal(tk4.cpu().numpy()[0, :n], tk1[i, :n])
     np.testing.assert_array_equal(lp4.cpu().numpy()[0, :n], lp1[i, :n])
+    # (c) a short utterance against the ORACLE (OracleNet on the CPU): the first 150 frames of utterance 5 as an utterance
+    # of their own - tokens, encoded length, log-probs
+    xs = x[i:i + 1, :, :150].contiguous()
+    lp5, tk5, el5 = e.forward(xs, torch.tensor([150]))
+    net = O.OracleNet(topology.conv_plan(cfg), cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    want = net.forward(xs.cpu().numpy(), [150])
+    n = int(want['enc_len'][0])
+    assert int(el5[0]) == n == 75
+    assert np.array_equal(tk5.cpu().numpy()[0, :n], want['tokens'][0, :n])
+    np.testing.assert_allclose(lp5.cpu().numpy()[0, :n], want['log_probs'][0, :n], rtol=1e-4, atol=5e-5)
     e.close()
 
 
@@ -222,11 +235,7 @@ def test_fused_stem_and_decoder_match_unfused(eng, golden_dir):
              (3, 501, [501, 2, 77]), (2, 33, [33, 1]), (1, 129, [100])]    # odd frame counts, 1- and 2-frame utterances
     outs = []
     for stem, dec in ((1, 1), (0, 0)):
-        os.environ['QASR_NO_FUSE_STEM'], os.environ['QASR_NO_FUSE_DEC'] = str(1 - stem), str(1 - dec)
-        try:
-            e = eng.Engine(blob, 0)
-        finally:
-            del os.environ['QASR_NO_FUSE_STEM'], os.environ['QASR_NO_FUSE_DEC']
+        e = eng.Engine(blob, 0, fuse_stem=bool(stem), fuse_decoder=bool(dec))      # qasr_engine_opts, not the environment
         res = []
         for B, T, ls in cases:
             x = torch.from_numpy(synth.make_features(B, 64, T, 13 + T)).cuda()
@@ -401,9 +410,10 @@ def test_graph_replay_matches_direct_launches(eng, golden_dir):
 
 
 def test_requant_fast_path_adversarial(eng):
-    """qasr_requant runs the production requant_batch (float32 product, tie-window vote, fp64 fallback).  Inputs built to
-    sit ON and next to rounding ties (z*M = k + 1/2 exactly, and one float32 ulp away from it), beyond the clamp range,
-    and with multipliers whose float32 image rounds the other way - against numpy fp64 round-half-even."""
+    """qasr_requant runs the production requant_batch: t = fma(f64(z), M, 1.5 * 2^52), clamp in the double domain, low
+    mantissa word (csrc/qasr_device.h; fixedpoint_mul, quant_utils.py:196-198).  Inputs built to sit ON and next to rounding
+    ties (z*M = k + 1/2 exactly, and the nearest integers z on either side of it), beyond the clamp range, and with
+    (m, e) multipliers as batch_frexp makes them - against numpy fp64 round-half-even."""
     rng = np.random.default_rng(11)
     C, T = 64, 256
     M = np.empty(C)
@@ -432,23 +442,12 @@ GENERATIONS = [dict(gen=2), dict(gen=2, wide_tiles=True, tile128=0), dict(gen=2,
 GEN_IDS = ['k_sep2_32', 'k_sep2_64', 'k_sep2_128', 'k_sep_32', 'k_sep_64', 'k_utt']
 
 
-def _engine_gen(eng, blob, gen, tile128=None, **kw):
-    """QASR_SEP_GEN / QASR_TILE128 are read at engine creation: gen 1 keeps every separable layer on k_sep, 2 (default)
-    routes the stride-1 layers with 256 / 512 input channels to k_sep2; with wide tiles, tile128 = 1 puts k_sep2's plain
-    layers (and Jasper's plain dense convs) on 128-frame tiles, 0 keeps everything on 64."""
-    env = {'QASR_SEP_GEN': str(gen)}
-    if tile128 is not None:
-        env['QASR_TILE128'] = str(tile128)
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return eng.Engine(blob, 0, **kw)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
+def _engine_gen(eng, blob, gen, tile128=None, wide_tiles=False, **kw):
+    """Kernel family and tile size through qasr_engine_opts (include/qasr.h): gen 1 keeps every separable layer on k_sep,
+    2 (default) routes the stride-1 layers with 256 / 512 input channels to k_sep2; with wide tiles, tile128 = 1 puts
+    k_sep2's separable layers (and Jasper's plain dense convs) on 128-frame tiles, 0 keeps everything on 64."""
+    tile = 32 if not wide_tiles else (64 if tile128 == 0 else 128)
+    return eng.Engine(blob, 0, sep_gen=gen, tile=tile, **kw)
 
 
 @pytest.fixture(scope='module')
@@ -493,6 +492,51 @@ def test_quartznet_t500_every_accumulator(eng, oracle_quartznet_t500, family):
         n = int(want['enc_len'][b])
         assert np.array_equal(tokens.cpu().numpy()[b, :n], want['tokens'][b, :n])
         np.testing.assert_allclose(logp.cpu().numpy()[b, :n], want['log_probs'][b, :n], rtol=1e-4, atol=5e-5)
+    e.close()
+
+
+@pytest.fixture(scope='module', params=[('net_quartznet_w8a8', 8, 8), ('net_quartznet_w6a6', 6, 6)], ids=['w8a8', 'w6a6'])
+def oracle_full_size(request, golden_dir):
+    """oracle.fakequant_torch.FakeQuantNet (the reference's fake-quant op sequence, pinned by tests/test_oracle_golden.py)
+    on BASELINE.json's config 2 / config 3 shape: 32 utterances x 500 frames, ragged lengths."""
+    from oracle.fakequant_torch import FakeQuantNet
+    name, wbit, abit = request.param
+    d, meta = _load(golden_dir, name)
+    cfg = topology.quartznet15x5()
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    B, T = 32, 500
+    x = synth.make_features(B, 64, T, 21)
+    lens = [T - 11 * (i % 13) - (i % 3) for i in range(B)]      # 365 .. 500: lengths inside every tile of the last 128 frames
+    lens[3], lens[17] = 500, 129                               # a full utterance and one that ends one frame into tile 1
+    net = FakeQuantNet(topology.conv_plan(cfg), cfg, sd, d['act_min'], d['act_max'], wbit, abit)
+    want = net.forward(x, lens)
+    blob, pm = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], wbit, abit)
+    return dict(x=x, lens=lens, want=want, blob=blob, pm=pm, wbit=wbit)
+
+
+@pytest.mark.parametrize('opts', [dict(tile=32), dict(tile=128), dict(tile=128, persistent=True)], ids=['tile32', 'tile128', 'persistent'])
+def test_production_engine_full_size_against_oracle(eng, oracle_full_size, opts):
+    """The NON-debug engine (production instantiations: pipelined depthwise stage, packed-code masks, no accumulator hooks)
+    at full size, w8a8 and w6a6, against the CPU oracle: tokens, encoded lengths, log-probs (rtol 1e-4) and the final
+    encoder codes (the decoder's input, qasr_engine_read_tensor) on every valid frame."""
+    o = oracle_full_size
+    e = eng.Engine(o['blob'], 0, **opts)
+    logp, tokens, enc_len = e.forward(torch.from_numpy(o['x']).cuda(), torch.tensor(o['lens']))
+    torch.cuda.synchronize()
+    labels = e.op_labels()
+    assert not any('true' in l for l in labels), labels        # no debug instantiation anywhere
+    tt = f", {opts['tile']}>"
+    assert sum(l.startswith('k_sep2<') and l.endswith(tt) for l in labels) >= 60, labels
+    want = o['want']
+    wl = want['enc_len'].numpy()
+    assert np.array_equal(enc_len.cpu().numpy(), wl)
+    codes = e.read_tensor(o['pm']['dec_in'], 1024)
+    tk, lp = tokens.cpu().numpy(), logp.cpu().numpy()
+    for b in range(len(wl)):
+        n = int(wl[b])
+        assert np.array_equal(codes[b, :, :n], want['enc_codes'][b, :, :n].numpy().astype(np.int8)), b
+        assert np.array_equal(tk[b, :n], want['tokens'][b, :n].numpy()), b
+        np.testing.assert_allclose(lp[b, :n], want['log_probs'][b, :n].numpy(), rtol=1e-4, atol=5e-5)
     e.close()
 
 
