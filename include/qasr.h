@@ -199,6 +199,9 @@ int qasr_engine_forward_audio(qasr_engine* e, void* stream, const float* audio, 
                               int32_t* tokens, int32_t* lens_out);
 int qasr_engine_out_frames(const qasr_engine* e, int T);
 int qasr_engine_num_ops(const qasr_engine* e);
+/* kernel launches of one forward of the current plan (encoder + decoder, without the two front-end launches of
+ * qasr_engine_forward_audio): 80 for QuartzNet15x5 with the default options, 7 with `persistent`; -1 before the first forward */
+int qasr_engine_num_launches(const qasr_engine* e);
 
 /* Parity hooks (debug engines only; synchronise the stream).  acc: int32 [B][cout][T_out] = the
  * value rint(conv_int) of QuantConv1d.int_conv (quant_modules.py:304) for op `op` (pane < 0: main conv). */

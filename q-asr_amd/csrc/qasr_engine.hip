@@ -111,6 +111,11 @@ struct qasr_engine {
   int32_t* r32 = nullptr;              // scratch [B][max cout][Tp] of the residual pair
   // hipGraph replay (bit 4 of `debug`): the whole forward of one (shape, buffer set) is captured once and re-launched
   // with one call; key = the caller's pointers, which a serving loop keeps stable
+  // persistent mode: runs of consecutive k_sep2 layers launched as one kernel (qasr_sep2_mega.hip)
+  struct MegaRun { uint32_t first = 0, last = 0; int n = 0; MegaOp* dev = nullptr; size_t smem = 0; };
+  std::vector<MegaRun> mega_runs;
+  std::vector<int> mega_of;            // per op: index into mega_runs, or -1
+  bool mega_built = false;
   bool use_graph = false;
   hipGraphExec_t gexec = nullptr;
   const void* gkey[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -153,6 +158,11 @@ static void free_plan(qasr_engine* e) {
   e->acc_dbg.clear();
   e->tens.clear();
   e->B = e->T0 = 0;
+  for (auto& r : e->mega_runs)
+    if (r.dev) (void)hipFree(r.dev);
+  e->mega_runs.clear();
+  e->mega_of.clear();
+  e->mega_built = false;
 }
 
 static int build_plan(qasr_engine* e, int B, int T0) {
@@ -510,6 +520,20 @@ void qasr_engine_destroy(qasr_engine* e) {
 
 int qasr_engine_num_ops(const qasr_engine* e) { return e ? (int)e->h.n_ops : -1; }
 
+int qasr_engine_num_launches(const qasr_engine* e) {
+  if (!e || !e->B || !e->mega_built) return -1;
+  int n = e->stem ? 0 : 1;                                   // (k_lens, which the stem absorbs)
+  for (uint32_t oi = 0; oi < e->h.n_ops; ++oi) {
+    if (e->mega_of[oi] >= 0) {
+      n += oi == e->mega_runs[e->mega_of[oi]].first;
+      continue;
+    }
+    if (e->skip[oi] || e->dec_skip[oi] || e->rq_skip[oi] || (e->stem && oi >= 1 && oi <= 2)) continue;
+    n += (e->utt[oi] == 2) ? 2 : 1;
+  }
+  return n;
+}
+
 int qasr_engine_out_frames(const qasr_engine* e, int T) {
   if (!e) return -1;
   std::vector<int> dT(e->h.n_domains);
@@ -784,6 +808,58 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
   return QASR_OK;
 }
 
+// Persistent mode: maximal runs of consecutive ops the persistent kernel has a shape for (fused depthwise ops in between
+// run inside their 1x1 op's layer); a run of one layer gains nothing and stays a plain launch.  The parameter blocks hold
+// arena / blob pointers only (tensor 0, the caller's feature buffer, feeds the stem, never a separable layer), so they
+// are built once per plan.
+static int build_mega(qasr_engine* e) {
+  e->mega_built = true;
+  e->mega_of.assign(e->h.n_ops, -1);
+  if (!e->persistent || e->debug || e->timing || e->use_utt) return QASR_OK;
+  std::vector<MegaOp> cur;
+  std::vector<uint32_t> members;
+  uint32_t first = 0;
+  auto close = [&]() -> int {
+    if (cur.size() >= 2) {
+      qasr_engine::MegaRun r;
+      r.first = first;
+      r.last = members.back();
+      r.n = (int)cur.size();
+      for (const MegaOp& m : cur) r.smem = std::max(r.smem, sep2_mega_smem(m.p));
+      HIPCHK(hipMalloc((void**)&r.dev, cur.size() * sizeof(MegaOp)));
+      HIPCHK(hipMemcpy(r.dev, cur.data(), cur.size() * sizeof(MegaOp), hipMemcpyHostToDevice));
+      for (uint32_t oi = r.first; oi <= r.last; ++oi) e->mega_of[oi] = (int)e->mega_runs.size();
+      e->mega_runs.push_back(r);
+    }
+    cur.clear();
+    members.clear();
+    return QASR_OK;
+  };
+  for (uint32_t oi = 0; oi < e->h.n_ops; ++oi) {
+    if (e->skip[oi] && !cur.empty()) continue;               // a depthwise op fused into the next op: inside the run
+    int shape = -1;
+    MegaOp m{};
+    if (!e->skip[oi] && !(e->stem && oi <= 2) && e->ops[oi].kind == QASR_OP_PW && e->fused_dw[oi] >= 0) {
+      build_sep(e, oi, m.p);
+      m.p.prof = nullptr;
+      m.p.prof_mode = 0;
+      shape = sep2_mega_shape(m.p);
+    }
+    if (shape < 0) {
+      if (!e->skip[oi]) {
+        int rc = close();
+        if (rc) return rc;
+      }
+      continue;
+    }
+    if (cur.empty()) first = e->fused_dw[oi] >= 0 ? (uint32_t)e->fused_dw[oi] : oi;
+    m.shape = shape;
+    cur.push_back(m);
+    members.push_back(oi);
+  }
+  return close();
+}
+
 // front-end of a forward_audio call (nullptr: the caller's features are the input)
 struct FrontArgs {
   const float* audio;
@@ -821,11 +897,23 @@ static int forward_impl(qasr_engine* e, hipStream_t s, const FrontArgs* fe, floa
     if (!e->stem) launch_lens(s, lens, e->lens_all, ddoms, (int)h.n_domains, B);   // (k_stem derives them itself)
     for (uint32_t oi = 0; oi < h.n_ops; ++oi) {
       if (e->timing) HIPCHK(hipEventRecord(e->ev[oi], s));
+      if (e->mega_of[oi] >= 0) {                             // a run of separable layers: one persistent launch at its first op
+        const qasr_engine::MegaRun& r = e->mega_runs[e->mega_of[oi]];
+        if (oi == r.first) {
+          int rc = launch_sep2_mega(s, r.dev, r.n, B, r.smem);
+          if (rc) return fail(rc, "persistent launch of ops %u..%u", r.first, r.last);
+        }
+        continue;
+      }
       int rc = launch_op(e, s, oi, logp, tokens, lens_out);
       if (rc) return rc;
     }
     return QASR_OK;
   };
+  if (!e->mega_built) {
+    int rc = build_mega(e);
+    if (rc) return rc;
+  }
   if (e->use_graph && s != nullptr && !e->timing && !e->debug) {   // the legacy default stream cannot be captured
     const void* key[8] = {feats, lens, logp, tokens, lens_out, fe ? fe->audio : nullptr, fe ? fe->audio_lens : nullptr,
                           fe ? fe->plan : nullptr};

@@ -93,6 +93,15 @@ struct SepP {             // fused separable layer: depthwise stencil -> QuantAc
   EpiP e;
 };
 
+// one layer of a persistent launch (qasr_sep2_mega.hip): k_sep2's parameter block + the shape to instantiate, in device memory
+struct MegaOp {
+  int shape, pad_[3];
+  SepP p;
+};
+int sep2_mega_shape(const SepP& p);                    // >= 0: the persistent kernel has this op's shape
+size_t sep2_mega_smem(const SepP& p);
+int launch_sep2_mega(hipStream_t s, const MegaOp* dev_ops, int n_ops, int B, size_t smem);
+
 extern long long* g_prof;
 extern int g_prof_mode;
 extern int g_prof_cap;      // timeline mode: work-groups the buffer holds (4 int64 each)

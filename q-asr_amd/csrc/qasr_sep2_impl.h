@@ -256,8 +256,11 @@ struct Sep2PassP {
 // K taps, NG groups of 128 input channels (cin_pad = 128 NG), NGP groups of the residual 1x1 conv (0: no res_act),
 // NP passes of 256 output channels - all compile-time: the whole kernel is straight-line code, which is what lets the
 // compiler count its s_waitcnt vmcnt(N) exactly instead of draining every prefetch at each join
+// The work of ONE work-group: utterance b, frames [t0, t0 + TT), every channel.  k_sep2 below runs it once per work-group
+// of a (B, Tp / TT) grid; the persistent kernel (qasr_sep2_mega.hip) walks layers and time tiles with it.  `p` may live
+// in the kernel-argument segment or in global memory: its address is wave-uniform either way (scalar loads).
 template <int K, int NG, int NGP, int NP, bool DBG, int TT>
-__global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
+__device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int t0, const bool stamp_wg, const int wg_id) {
   using G = Sep2Geo<K, TT>;
   constexpr bool RES = NGP > 0;
   constexpr int MT = TT / 32;
@@ -266,9 +269,12 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   constexpr int NCHUNK = (CIN_PAD + SEP2_CH - 1) / SEP2_CH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const EpiP& e = p.e;
-  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  int tid_ = threadIdx.x;
+  // (persistent kernel: every lane-derived constant is recomputed inside the call - hoisted out of the layer loop they
+  //  would stay live across all bodies and push the 245-251 VGPR ones into spilling)
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x, t0 = blockIdx.y * TT;
   lds_u8* const Xd = (lds_u8*)smem;                          // [MT][CIN_PAD][32]  A image of the 1x1 conv
   // depthwise operands are wave-private: wave w stages the window and tap rows of ITS 16 channels of a group in its own
   // region [16][WP] + [16][KS] - no work-group barrier before the A image is complete; afterwards the region holds the
@@ -288,7 +294,7 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   // fetched NOW: left to the compiler the scalar load sits in front of the first requantisation, and its
   // s_waitcnt lgkmcnt(0) (scalar loads return out of order) also waits for the next group's LDS reads issued just before
   asm volatile("" : "+v"(dw_lo), "+v"(dw_hi));               // (as VGPRs: v_med3_i32's operands; "+s" breaks the debug build)
-  const bool stamp = p.prof && (p.prof_mode & 255) == 0 && blockIdx.x == 0 && blockIdx.y == 1 && tid == 0;
+  const bool stamp = p.prof && (p.prof_mode & 255) == 0 && stamp_wg && tid == 0;
   const bool tline = p.prof && (p.prof_mode & 255) == 1 && tid == 0;
   const int tune = p.prof_mode >> 8;                          // QASR_SEP2_TUNE (experiments)
   long long tl_start = 0, tl_clk = 0;
@@ -848,14 +854,20 @@ __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
   }
   }
   if (stamp) p.prof[31] = nst;
-  if (tline && (int)(blockIdx.y * gridDim.x + blockIdx.x) < p.prof_cap) {
-    long long* r = p.prof + 4 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
+  if (tline && wg_id < p.prof_cap) {
+    long long* r = p.prof + 4 * (size_t)wg_id;
     r[0] = tl_start;
     r[1] = (long long)__builtin_amdgcn_s_memrealtime();
     r[3] = (long long)__builtin_amdgcn_s_memtime() - tl_clk;     // shader cycles of the work-group: / (r[1] - r[0]) = clock / 100 MHz
     r[2] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(6164) << 32);   // HW_ID, XCC_ID
   }
 #undef STAMP2
+}
+
+template <int K, int NG, int NGP, int NP, bool DBG, int TT>
+__global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
+  sep2_body<K, NG, NGP, NP, DBG, TT>(p, blockIdx.x, blockIdx.y * TT, blockIdx.x == 0 && blockIdx.y == 1,
+                                     blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 template <int K, int TT>
@@ -874,6 +886,17 @@ static inline size_t sep2_smem_bytes(const SepP& p) {
   X(33, 2, 0, 1) X(39, 2, 0, 1) X(51, 2, 0, 2) X(51, 4, 0, 2) X(63, 4, 0, 2) X(75, 4, 0, 2) \
   X(33, 2, 2, 1) X(39, 2, 2, 1) X(51, 4, 2, 2) X(51, 4, 4, 2) X(63, 4, 4, 2) X(75, 4, 4, 2) \
   X(0, 4, 0, 4)
+
+// position of (taps, groups, residual groups, passes) in SEP2_INSTANCES, -1: none (the persistent kernel's switch value)
+constexpr int sep2_shape_index(int K, int NG, int NGP, int NP) {
+  int i = 0;
+#define SEP2_IDX(K_, NG_, NGP_, NP_) \
+  if (K == K_ && NG == NG_ && NGP == NGP_ && NP == NP_) return i; \
+  ++i;
+  SEP2_INSTANCES(SEP2_IDX)
+#undef SEP2_IDX
+  return -1;
+}
 
 // Shapes k_sep2 is built for; everything else stays on k_sep.
 static inline bool sep2_shape_ok(const SepP& p) {

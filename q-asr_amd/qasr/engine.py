@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('QASR_LIB', os.path.join(HERE, 'libqasr_hip.so'))   # QASR_LIB: A/B builds in one run
 
 SYMBOLS = ['qasr_engine_create', 'qasr_engine_create_ex', 'qasr_engine_default_opts', 'qasr_engine_destroy', 'qasr_engine_forward', 'qasr_engine_forward_audio', 'qasr_engine_out_frames',
-           'qasr_engine_num_ops', 'qasr_engine_read_acc', 'qasr_engine_read_tensor', 'qasr_engine_last_op_ms',
+           'qasr_engine_num_ops', 'qasr_engine_num_launches', 'qasr_engine_read_acc', 'qasr_engine_read_tensor', 'qasr_engine_last_op_ms',
            'qasr_engine_time_ops', 'qasr_engine_run_op', 'qasr_engine_op_label',
            'qasr_frontend_mel', 'qasr_frontend_plan', 'qasr_frontend_mel_planned', 'qasr_frontend_frames',
            'qasr_frontend_workspace_bytes', 'qasr_pw_conv_acc',
@@ -69,6 +69,7 @@ def load_library():
     lib.qasr_engine_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.qasr_engine_out_frames.argtypes = [vp, i32]
     lib.qasr_engine_num_ops.argtypes = [vp]
+    lib.qasr_engine_num_launches.argtypes = [vp]
     lib.qasr_engine_read_acc.argtypes = [vp, i32, i32, vp, sz]
     lib.qasr_engine_read_tensor.argtypes = [vp, i32, vp, sz, C.POINTER(i32), C.POINTER(i32)]
     lib.qasr_engine_last_op_ms.argtypes = [vp, vp, i32]
@@ -166,6 +167,10 @@ class Engine:
 
     def out_frames(self, T):
         return self.lib.qasr_engine_out_frames(self._h, int(T))
+
+    def num_launches(self):
+        """kernel launches of one forward of the current plan (after a forward)"""
+        return self.lib.qasr_engine_num_launches(self._h)
 
     def forward(self, feats: torch.Tensor, lens: torch.Tensor, want_logp=True, stream=None, out=None):
         """feats f32 [B, feat_in, T] (cuda, contiguous), lens [B] -> (log_probs [B,T',C], tokens [B,T'], enc_len [B])."""

@@ -259,27 +259,41 @@ class Packer:
             if v.kind == 'acc' and (prod['flags'] & F_RESADD):
                 continue          # the accumulator of a RESADD op is consumed inside the op; its 'q' value has the outs
             mode = 1 if v.kind == 'acc' else 0
-            cons = v.consumers
-            if len(cons) <= MAX_OUTS:
-                for c in cons:
-                    dt = DT_U8 if c.hi > 127 else DT_S8
-                    c.tensor = self._tensor(v.channels, dt, v.domain, v.op)
-                    M = Q.requant_multiplier(v.scale, c.s_x)
-                    outs.append(dict(tensor=c.tensor, lo=max(c.lo, 0) if self._nonneg(prod) else c.lo, hi=c.hi,
-                                     mode=mode, M=M))
+            # Consumers whose QuantAct ended up with the SAME range and width read the same integers: a block's output
+            # feeds the next block's first conv and the residual convs of later blocks, each behind a QuantAct of its own
+            # that was calibrated on that very tensor (jasper.py:664-676) - identical x_min / x_max, identical
+            # (multiplier, clamp).  Such consumers share ONE stored tensor (compared on the exact float64 multipliers and
+            # clamp bounds: a checkpoint whose ranges differ keeps them apart).
+            groups = []                                    # [(key, dtype, lo, hi, M, [consumers])]
+            for c in v.consumers:
+                dt = DT_U8 if c.hi > 127 else DT_S8
+                M = Q.requant_multiplier(v.scale, c.s_x)
+                lo = max(c.lo, 0) if self._nonneg(prod) else c.lo
+                key = (dt, lo, c.hi, np.asarray(M, dtype=np.float64).tobytes())
+                for g in groups:
+                    if g[0] == key:
+                        g[5].append(c)
+                        break
+                else:
+                    groups.append((key, dt, lo, c.hi, M, [c]))
+            if len(groups) <= MAX_OUTS:
+                for _, dt, lo, hi, M, members in groups:
+                    t = self._tensor(v.channels, dt, v.domain, v.op)
+                    for c in members:
+                        c.tensor = t
+                    outs.append(dict(tensor=t, lo=lo, hi=hi, mode=mode, M=M))
             else:
                 raw_dt = DT_I32 if v.kind == 'acc' else DT_S8
                 raw = self._tensor(v.channels, raw_dt, v.domain, v.op)
                 outs.append(dict(tensor=raw, lo=0, hi=0, mode=3 if v.kind == 'acc' else 2, M=None))
-                for c in cons:
-                    dt = DT_U8 if c.hi > 127 else DT_S8
-                    c.tensor = self._tensor(v.channels, dt, v.domain, -2)
-                    M = Q.requant_multiplier(v.scale, c.s_x)
+                for _, dt, lo, hi, M, members in groups:
+                    t = self._tensor(v.channels, dt, v.domain, -2)
+                    for c in members:
+                        c.tensor = t
                     extra.setdefault(v.op, []).append(dict(
                         kind=OP_REQUANT, flags=(prod['flags'] & (F_MASK_OUT | F_EXACT_Z)), in_tensor=raw,
                         cin=v.channels, cout=v.channels, s_b=v.scale if v.kind == 'acc' else None,
-                        outs=[dict(tensor=c.tensor, lo=max(c.lo, 0) if self._nonneg(prod) else c.lo, hi=c.hi,
-                                   mode=mode, M=M)]))
+                        outs=[dict(tensor=t, lo=lo, hi=hi, mode=mode, M=M)]))
         for i, op in enumerate(self.ops):
             remap[i] = len(final_ops)
             final_ops.append(op)

@@ -527,6 +527,9 @@ def test_production_engine_full_size_against_oracle(eng, oracle_full_size, opts)
     assert not any('true' in l for l in labels), labels        # no debug instantiation anywhere
     tt = f", {opts['tile']}>"
     assert sum(l.startswith('k_sep2<') and l.endswith(tt) for l in labels) >= 60, labels
+    # QuartzNet15x5: ~80 launches layer by layer; persistent: stem, blocks 1-15 as ONE launch, block 16, block 17, decoder
+    n_launch = e.num_launches()
+    assert (n_launch <= 6) if opts.get('persistent') else (78 <= n_launch <= 82), n_launch
     want = o['want']
     wl = want['enc_len'].numpy()
     assert np.array_equal(enc_len.cpu().numpy(), wl)
