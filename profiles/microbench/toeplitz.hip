@@ -231,7 +231,18 @@ k_tz(const uint8_t* __restrict__ x, const uint8_t* __restrict__ trows, int8_t* _
 // --------------------------------------------------------------------------------------------- k_sep2's 4x4x4 stage
 // (qasr_sep2_impl.h: wave-private rows, aligned lane streams, the previous group's requantisation one instruction behind
 //  every MFMA - the production code path of round 2, lifted out of k_sep2 with the same geometry Sep2Geo<K, 128>)
-template <int K>
+// 16 six-bit codes (12 bytes: 4 codes per 3 bytes, little-endian bit order as QASR_F_W6PACK) -> 16 bytes
+__device__ __forceinline__ unsigned spread6(unsigned g) {
+  return (g & 0x3fu) | ((g & 0xfc0u) << 2) | ((g & 0x3f000u) << 4) | ((g & 0xfc0000u) << 6);
+}
+__device__ __forceinline__ v4i unpack6x16(unsigned a, unsigned b, unsigned c) {
+  const unsigned g1 = __builtin_amdgcn_alignbit(b, a, 24), g2 = __builtin_amdgcn_alignbit(c, b, 16);
+  return (v4i){(int)spread6(a), (int)spread6(g1), (int)spread6(g2), (int)spread6(c >> 8)};
+}
+
+// PACK6: BASELINE config 3 "to the letter" for the activations - the input rows hold 4 six-bit codes per 3 bytes
+// ([C][Tp * 3 / 4]) and are unpacked where the stage touches every staged dword anyway (A/B of the stage)
+template <int K, bool PACK6 = false>
 __global__ void __launch_bounds__(512, 2)
 k_old(const uint8_t* __restrict__ x, const int8_t* __restrict__ wdw2, const int* __restrict__ bias_dw, const double* __restrict__ m_dw,
       int8_t* __restrict__ img, long long* __restrict__ prof, int T, int dw_lo, int dw_hi, int dump) {
@@ -259,7 +270,7 @@ k_old(const uint8_t* __restrict__ x, const int8_t* __restrict__ wdw2, const int*
     const int pi = lane + 64 * i;
     const int row = pi / G::NPG, col = pi - row * G::NPG;
     const int t = t0 - G::HALO + 16 * col;
-    woff[i] = min(row, 15) * eTp + min(max(t, 0), eTp - 16);
+    woff[i] = PACK6 ? min(row, 15) * (eTp * 3 / 4) + min(max(t, 0), eTp - 16) / 16 * 12 : min(row, 15) * eTp + min(max(t, 0), eTp - 16);
     wkeep[i] = (t >= 0 && t < eTp) ? 0xffffffffu : 0u;
     wlds[i] = Wsw + min(row, 15) * G::WP + 16 * col;
     asm volatile("" : "+v"(wkeep[i]));
@@ -268,10 +279,17 @@ k_old(const uint8_t* __restrict__ x, const int8_t* __restrict__ wdw2, const int*
   for (int i = 0; i < G::NTT; ++i) toff[i] = 16 * min(lane + 64 * i, G::KS - 1);
   auto ld_grp = [&](int g) {
     const int cw = SEP2_CH * g + 16 * wave;
-    const uint8_t* const xg = x + ((size_t)b * CIN_PAD + cw) * eTp;
+    const uint8_t* const xg = x + ((size_t)b * CIN_PAD + cw) * (PACK6 ? eTp * 3 / 4 : eTp);
     const unsigned char* const tg = (const unsigned char*)wdw2 + (size_t)cw * G::KS;
 #pragma unroll
-    for (int i = 0; i < G::NPT; ++i) pc[i] = *(const v4i*)(xg + woff[i]);
+    for (int i = 0; i < G::NPT; ++i) {
+      if constexpr (PACK6) {
+        const unsigned* q = (const unsigned*)(xg + woff[i]);   // 12 bytes, 4-byte aligned: global_load_dwordx3
+        pc[i] = (v4i){(int)q[0], (int)q[1], (int)q[2], 0};
+      } else {
+        pc[i] = *(const v4i*)(xg + woff[i]);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < G::NTT; ++i) pt[i] = *(const v4i*)(tg + toff[i]);
   };
@@ -280,6 +298,7 @@ k_old(const uint8_t* __restrict__ x, const int8_t* __restrict__ wdw2, const int*
     for (int i = 0; i < G::NPT; ++i) {
       if (64 * i + 63 < 16 * G::NPG || lane + 64 * i < 16 * G::NPG) {
         v4i v = pc[i];
+        if constexpr (PACK6) v = unpack6x16((unsigned)v[0], (unsigned)v[1], (unsigned)v[2]);
         v[0] = (v[0] & wkeep[i]) ^ flip; v[1] = (v[1] & wkeep[i]) ^ flip; v[2] = (v[2] & wkeep[i]) ^ flip; v[3] = (v[3] & wkeep[i]) ^ flip;
         *(lds_v4i*)wlds[i] = v;
       }
@@ -532,13 +551,13 @@ static void bench_k(int B) {
     return bad == 0;
   };
   const size_t smem_old = (size_t)TILE * NCH + 8 * GO::WREG;
-  CK(hipFuncSetAttribute((const void*)k_old<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_old<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute((const void*)k_tz<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute((const void*)k_tz<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   printf("K = %d, %d work-groups (512 threads, 512 channels x 128 frames each): Toeplitz NS = %d MFMA steps per channel pair, LDS %zu B; "
          "4x4x4: %d MFMAs per 16 channels, LDS %zu B\n", K, 2 * B, G::NS, G::SMEM, GO::NS * GO::NU, smem_old);
   CK(hipMemset(dimg, 0x55, ref.size()));
-  Times to = run([&](int dump) { hipLaunchKernelGGL((k_old<K>), grid, blk, smem_old, 0, dx, dw2, dbias, dM, dimg, dprof, T, lo, hi, dump); }, dprof, 2 * B, 50);
+  Times to = run([&](int dump) { hipLaunchKernelGGL((k_old<K, false>), grid, blk, smem_old, 0, dx, dw2, dbias, dM, dimg, dprof, T, lo, hi, dump); }, dprof, 2 * B, 50);
   check("4x4x4 (k_sep2 r02)");
   CK(hipMemset(dimg, 0x55, ref.size()));
   Times t1 = run([&](int dump) { hipLaunchKernelGGL((k_tz<K, false>), grid, blk, G::SMEM, 0, dx, dtr, dimg, dprof, T, lo, hi, dump); }, dprof, 2 * B, 50);
@@ -556,6 +575,70 @@ static void bench_k(int B) {
   CK(hipFree(dx)); CK(hipFree(dtr)); CK(hipFree(dw2)); CK(hipFree(dimg)); CK(hipFree(dbias)); CK(hipFree(dM)); CK(hipFree(dprof));
 }
 
+// BASELINE config 3 activations: the same stage on 6-bit codes [0, 63], rows one byte per code vs 4 codes per 3 bytes
+template <int K>
+static void bench_pack6(int B) {
+  using GO = Sep2Geo<K, TILE>;
+  const int T = 250, lo = -32, hi = 31;
+  std::mt19937 rng(K * 31 + 5);
+  std::vector<uint8_t> x((size_t)B * NCH * TPR, 0), xp((size_t)B * NCH * TPR * 3 / 4 + 256, 0);
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < NCH; ++c) {
+      uint8_t* r = &x[((size_t)b * NCH + c) * TPR];
+      for (int t = 0; t < T; ++t) r[t] = (uint8_t)(rng() & 63);
+      uint8_t* q = &xp[((size_t)b * NCH + c) * (TPR * 3 / 4)];
+      for (int t = 0; t < TPR; t += 4) {
+        const unsigned w = r[t] | (r[t + 1] << 6) | (r[t + 2] << 12) | (r[t + 3] << 18);
+        q[t / 4 * 3] = w & 255; q[t / 4 * 3 + 1] = (w >> 8) & 255; q[t / 4 * 3 + 2] = (w >> 16) & 255;
+      }
+    }
+  std::vector<int8_t> w((size_t)NCH * K);
+  for (auto& v : w) v = (int8_t)((int)(rng() % 62) - 31);
+  std::vector<double> M(NCH);
+  std::vector<int> bias(NCH);
+  for (int c = 0; c < NCH; ++c) {
+    const double mant = 0.5 + (rng() % (1u << 30)) / (double)(1u << 31);
+    M[c] = std::ldexp(std::floor(mant * 2147483648.0 + 0.5), -31 - 9 - (int)(rng() % 3));
+    int sum = 0;
+    for (int m = 0; m < K; ++m) sum += w[(size_t)c * K + m];
+    bias[c] = 128 * sum;
+  }
+  std::vector<int8_t> wdw2((size_t)NCH * GO::KS + 256, 0);
+  for (int c = 0; c < NCH; ++c) memcpy(&wdw2[(size_t)c * GO::KS + 8], &w[(size_t)c * K], K);
+  const std::vector<int8_t> ref = cpu_image(x, w, M, B, K, T, lo, hi);
+  uint8_t *dx, *dxp; int8_t *dw2, *dimg; int* dbias; double* dM; long long* dprof;
+  CK(hipMalloc(&dx, x.size() + 256)); CK(hipMalloc(&dxp, xp.size())); CK(hipMalloc(&dw2, wdw2.size()));
+  CK(hipMalloc(&dimg, ref.size())); CK(hipMalloc(&dbias, NCH * 4)); CK(hipMalloc(&dM, NCH * 8));
+  CK(hipMalloc(&dprof, (size_t)B * 2 * 8 * 4 * 8));
+  CK(hipMemcpy(dx, x.data(), x.size(), hipMemcpyHostToDevice));
+  CK(hipMemcpy(dxp, xp.data(), xp.size(), hipMemcpyHostToDevice));
+  CK(hipMemcpy(dw2, wdw2.data(), wdw2.size(), hipMemcpyHostToDevice));
+  CK(hipMemcpy(dbias, bias.data(), NCH * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dM, M.data(), NCH * 8, hipMemcpyHostToDevice));
+  const dim3 grid(B, 2), blk(512);
+  const size_t smem = (size_t)TILE * NCH + 8 * GO::WREG;
+  CK(hipFuncSetAttribute((const void*)k_old<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_old<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  auto check = [&](const char* name) {
+    std::vector<int8_t> got(ref.size());
+    CK(hipMemcpy(got.data(), dimg, got.size(), hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) bad += got[i] != ref[i];
+    printf("  %-34s parity vs CPU conv + requant: %s (%zu of %zu bytes differ)\n", name, bad ? "FAIL" : "bit-exact", bad, ref.size());
+  };
+  printf("K = %d, 6-bit codes [0, 63], %d work-groups: 4x4x4 stage, input rows one byte per code vs 4 codes per 3 bytes\n", K, 2 * B);
+  CK(hipMemset(dimg, 0x55, ref.size()));
+  Times t8 = run([&](int dump) { hipLaunchKernelGGL((k_old<K, false>), grid, blk, smem, 0, dx, dw2, dbias, dM, dimg, dprof, T, lo, hi, dump); }, dprof, 2 * B, 50);
+  check("one byte per code");
+  CK(hipMemset(dimg, 0x55, ref.size()));
+  Times t6 = run([&](int dump) { hipLaunchKernelGGL((k_old<K, true>), grid, blk, smem, 0, dxp, dw2, dbias, dM, dimg, dprof, T, lo, hi, dump); }, dprof, 2 * B, 50);
+  check("4 codes per 3 bytes (unpacked in staging)");
+  printf("  one byte per code          launch %7.2f us | work-group cycles until all waves done (median) %6lld\n", t8.us, t8.all);
+  printf("  4 codes per 3 bytes        launch %7.2f us | work-group cycles until all waves done (median) %6lld   (%+.1f %%)\n", t6.us, t6.all,
+         100.0 * ((double)t6.all / t8.all - 1.0));
+  CK(hipFree(dx)); CK(hipFree(dxp)); CK(hipFree(dw2)); CK(hipFree(dimg)); CK(hipFree(dbias)); CK(hipFree(dM)); CK(hipFree(dprof));
+}
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 32;
   printf("== depthwise stage of a 512-channel layer, %d utterances x 2 tiles of 128 frames\n", B);
@@ -564,5 +647,8 @@ int main(int argc, char** argv) {
   bench_k<51>(B);
   bench_k<63>(B);
   bench_k<75>(B);
+  printf("== sub-byte activations (BASELINE config 3): the round-2 stage with packed input rows\n");
+  bench_pack6<33>(B);
+  bench_pack6<75>(B);
   return 0;
 }
