@@ -1,0 +1,250 @@
+// k_dense2: Jasper's dense (non-separable) stride-1 'same' convs without residual panes (jasper.py:601-630: MaskedConv1d
+// -> BatchNorm (folded) -> ReLU), as taps-shifted 1x1 GEMMs on v_mfma_i32_32x32x32_i8 - the second-generation kernel for
+// the ops round 1's k_sep<0, 1, EP_PLAIN> ran (QuantConv1d.int_conv, quant_modules.py:301-305; the consumers' QuantAct
+// requantisation fixedpoint_mul, quant_utils.py:187-216, fused into the epilogue).
+//
+// Why a new decomposition.  k_sep's work-group is (utterance, 128 frames, EVERY output channel): each weight fragment a
+// wave loads feeds 4 MFMAs, a work-group streams the whole layer's weights (14.7 MB for 768 -> 768, k = 25) - 32 B/clk of
+// the CU's ~50 B/clk L2 -> register path at full matrix rate - and the generic kernel (256 VGPRs, 50 spilled) has no
+// registers left to read A fragments ahead: 0.46 of the int8 MFMA peak with the chip filled.  Here
+//   work-group = 256 threads = (utterance, 128 output channels, up to 256 frames); wave = 32 channels x up to 8 frame
+//   tiles of 32: every weight fragment feeds 8 MFMAs (16 B/clk per CU), 128 accumulators per lane;
+//   the window is staged per chunk of 128 input channels as Xs[frame][channel] (K contiguous: a tap shift is a row shift,
+//   every A fragment an aligned ds_read_b128), 46 KB: two or three work-groups per CU, one staging while the other multiplies;
+//   A fragments are read one K step ahead, weight fragments two (tap, chunk) items ahead.
+// Grid (B, cout_pad / 128, ceil(Tp / (32 MT))), utterance fastest (an utterance's rows stay in one XCD's L2; consecutive
+// work-groups share the weights of their channel block).
+#include "qasr_sep2_impl.h"
+
+namespace qasr {
+
+#define DENSE2_NT 256
+#define DENSE2_CK 128                   /* input channels per staged chunk */
+#define DENSE2_XP (DENSE2_CK + 16)      /* LDS row pitch: 16-byte aligned rows, rows 36 banks apart */
+
+// rows [tf, tf + rows) x channels [c0, c0 + 128) of x[B][cin][Tp] -> Xs[row][channel] (4 x 4 byte transposes; a task = 16
+// frames of 4 channels: four 16-byte loads, sixteen dword stores).  Frames outside [0, Tp) and channels >= cin read as code
+// 0 (conv zero padding; for u8 tensors the -128 flip makes that -128 everywhere, which the packer's +128 * sum(W) bias
+// assumes).  Lane map: 4 consecutive lanes take 4 consecutive 16-frame granules of the same channels (64 contiguous bytes
+// per row), the 16 lane quads of a wave 16 consecutive channel quads (64 contiguous LDS bytes per row: the 4 granules of a
+// quad fall on the same banks - a 4-way conflict on ds_write_b32 costs 2x, 20 lanes on one bank would cost 10x).  Every load
+// of a chunk is issued before the first transpose.
+template <int MT>
+__device__ __forceinline__ void dense2_stage(lds_u8* Xs, const int8_t* __restrict__ x, int cin, int Tp, int b, int c0, int tf, int rows,
+                                             unsigned flip) {
+  constexpr int MAXROWS = 32 * MT + 64, NTASK = (DENSE2_CK / 4) * ((MAXROWS / 16 + 3) / 4 * 4);
+  constexpr int NIT = (NTASK + DENSE2_NT - 1) / DENSE2_NT;
+  const int n16 = rows >> 4;
+  v4i r[NIT][4];
+  int cqs[NIT], tqs[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int task = threadIdx.x + DENSE2_NT * it;
+    const int cq = (task >> 2) & 31, tq = 4 * (task >> 7) + (task & 3);
+    cqs[it] = cq;
+    tqs[it] = tq;
+    const int t = tf + 16 * tq;
+    const bool t_ok = tq < n16 && t >= 0 && t < Tp;           // a 16-frame granule lies entirely inside or outside
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ci = c0 + 4 * cq + j;
+      r[it][j] = (ci < cin && t_ok) ? *(const v4i*)(x + ((size_t)b * cin + ci) * Tp + t) : (v4i){0, 0, 0, 0};
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (tqs[it] >= n16) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                             // frames 4 q .. 4 q + 3 of the granule
+      const unsigned r0 = r[it][0][q], r1 = r[it][1][q], r2 = r[it][2][q], r3 = r[it][3][q];
+      const unsigned lo01 = __builtin_amdgcn_perm(r1, r0, 0x05010400u), hi01 = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+      const unsigned lo23 = __builtin_amdgcn_perm(r3, r2, 0x05010400u), hi23 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+      lds_u8* dst = Xs + (16 * tqs[it] + 4 * q) * DENSE2_XP + 4 * cqs[it];
+      *(lds_u32*)(dst) = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u) ^ flip;
+      *(lds_u32*)(dst + DENSE2_XP) = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u) ^ flip;
+      *(lds_u32*)(dst + 2 * DENSE2_XP) = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u) ^ flip;
+      *(lds_u32*)(dst + 3 * DENSE2_XP) = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u) ^ flip;
+    }
+  }
+}
+
+template <int MT, bool DBG>
+__global__ void __launch_bounds__(DENSE2_NT, 2) k_dense2(SepP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  lds_u8* const Xs = (lds_u8*)smem;
+  const EpiP& e = p.e;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x, t0 = blockIdx.z * (32 * MT);
+  const int co_row = 128 * blockIdx.y + 32 * wave;           // this wave's 32 output channels (cout_pad is a multiple of 128)
+  const int co = co_row + r31;                               // MFMA C layout: channel = lane & 31
+  const int K = p.dense_k, dil = p.dilation, pad = dil * (K - 1) / 2;
+  const int halo = (pad + 15) & ~15, rows = 32 * MT + 2 * halo;
+  const int eT = e.T, eTp = e.Tp, ecout = e.cout, n_outs = e.n_outs, cin_pad = p.cin_pad;
+  const int cout_pad = (ecout + 127) & ~127;
+  const unsigned flags = e.flags;
+  const bool f_relu = flags & QASR_F_RELU, f_exact = flags & QASR_F_EXACT_Z;
+  const unsigned flip = p.pw_unsigned ? 0x80808080u : 0u;
+  const int lim = (flags & QASR_F_MASK_OUT) ? min(e.lens[b], eT) : eT;
+  const size_t tap_bytes = (size_t)cout_pad * cin_pad;
+  const int n_chunks = cin_pad / DENSE2_CK, n_items = n_chunks * K;
+
+  // per-lane parameters of its output channel
+  const int bias = p.bias[co];
+  const float sb = f_exact ? e.sb[co] : 1.0f;
+  double Mo[QASR_MAX_OUTS];
+#pragma unroll
+  for (int j = 0; j < QASR_MAX_OUTS; ++j) Mo[j] = j < n_outs ? e.outs[j].mtab[co] : 0.0;
+
+  v16i acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = bias;
+
+  // weight fragments of item i = (chunk, tap): the 4 K steps of the chunk, fragment order (pack.py:fragment_order), one
+  // fragment-ordered [cout_pad][cin_pad] matrix per tap (QASR_F_TAPMAJOR); two register sets, loaded one item (32 MT / 8
+  // MFMAs = 1 - 2 k cycles) ahead
+  v4i wa[4], wb[4];
+  auto load_w = [&](v4i (&w4)[4], int i) {
+    const int c = i / K, tap = i - c * K;
+    const v4i* wp = w_frag(p.w + tap * tap_bytes, cin_pad, co_row, 4 * c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w4[k] = wp[64 * k];
+  };
+  const lds_u8* const a_lane = Xs + r31 * DENSE2_XP + 16 * h;   // row (frame) r31 of a 32-frame tile, K half h
+  // A fragment of tile mt, K step ks of tap `tap`: rows 32 mt + tap * dil + (halo - pad) .., channels 32 ks + 16 h .. of the
+  // staged chunk.  Two register sets: the fragments of the NEXT K step - at the last step of a tap, of the next tap's first
+  // step - are all requested before this step's MFMAs issue (left alone, the compiler sinks every ds_read next to the MFMA
+  // that uses it and waits for it: one LDS latency per MFMA; without the hand-over between taps: one per 32 MFMAs, 15-20 %
+  // of the kernel parked at s_waitcnt by the SQ_WAIT_ANY counter)
+  v4i a[2][MT];
+  auto read_a = [&](v4i (&dst)[MT], int tap, int ks) {
+    const lds_u8* arow = a_lane + (halo - pad + tap * dil) * DENSE2_XP + 32 * ks;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) dst[mt] = *(const lds_v4i*)(arow + 32 * mt * DENSE2_XP);
+  };
+  auto run_item = [&](const v4i (&w4)[4], int i) {
+    const int c = i / K, tap = i - c * K;
+    if (tap == 0) {                                          // a new chunk of 128 input channels: stage its window
+      if (c > 0) __syncthreads();                            // every wave has read the previous chunk
+      dense2_stage<MT>(Xs, p.x, p.cin, eTp, b, DENSE2_CK * c, t0 - halo, rows, flip);
+      __syncthreads();
+      read_a(a[0], 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool more = tap + 1 < K;                           // (uniform)
+    sep2_for<0, 4>([&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      // one read of the next step's fragments behind every MFMA (its issue slot lies in the MFMA's 32-cycle shadow; a burst
+      // of 8 reads in front of the 8 MFMAs leaves the matrix pipe idle while it issues - one wave per SIMD and work-group)
+      const lds_u8* nrow = a_lane + (halo - pad + (ks + 1 < 4 ? tap : tap + 1) * dil) * DENSE2_XP + 32 * ((ks + 1) & 3);
+      sep2_for<0, MT>([&](auto mtc) {
+        constexpr int mt = decltype(mtc)::value;
+        acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks & 1][mt], w4[ks], acc[mt], 0, 0, 0);
+        if (ks + 1 < 4 || more) a[(ks + 1) & 1][mt] = *(const lds_v4i*)(nrow + 32 * mt * DENSE2_XP);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  };
+  load_w(wa, 0);
+  for (int i = 0; i < n_items; i += 2) {
+    if (i + 1 < n_items) load_w(wb, i + 1);
+    run_item(wa, i);
+    if (i + 2 < n_items) load_w(wa, i + 2);
+    if (i + 1 < n_items) run_item(wb, i + 1);
+  }
+
+  // ---- epilogue in the MFMA C layout (k_sep2's: requant, pack, two half-wave swaps, one 16-byte store per lane)
+  if (DBG && e.acc_dbg && co < ecout) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = t0 + 32 * mt + mfma32_row(r, h);
+        if (t < eT) e.acc_dbg[((size_t)b * ecout + co) * eTp + t] = acc[mt][r];
+      }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (t0 + 32 * mt >= eTp) continue;                       // (last time tile of a long utterance; uniform)
+    int z[16];
+    // z == acc below 2^22; a wave holding a larger accumulator takes fixedpoint_mul's float32 round trip
+    bool wide = false;
+    if (f_exact) {
+      int mx = acc[mt][0], mn = acc[mt][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) { mx = max(mx, acc[mt][r]); mn = min(mn, acc[mt][r]); }
+      wide = __any(mx >= (1 << 21) || mn < -(1 << 21));
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = wide ? z_roundtrip(acc[mt][r], sb, f_relu) : (f_relu ? max(acc[mt][r], 0) : acc[mt][r]);
+#pragma unroll
+    for (int j = 0; j < QASR_MAX_OUTS; ++j) {
+      if (j < n_outs) {
+        const OutP& o = e.outs[j];
+        const int olo = o.lo, ohi = o.hi;
+        unsigned P[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          P[g] = pack4b(requant_clamp(z[4 * g], Mo[j], olo, ohi), requant_clamp(z[4 * g + 1], Mo[j], olo, ohi),
+                        requant_clamp(z[4 * g + 2], Mo[j], olo, ohi), requant_clamp(z[4 * g + 3], Mo[j], olo, ohi));
+        const auto s02 = __builtin_amdgcn_permlane32_swap(P[0], P[2], false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(P[1], P[3], false, false);
+        v4i pk = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+        if (t0 + 32 * (mt + 1) > lim) pk = sep2_mask16(pk, lim - (t0 + 32 * mt + 16 * h));   // masked frames (uniform branch)
+        if (co < ecout) *(v4i*)((int8_t*)o.ptr + ((size_t)b * ecout + co) * eTp + t0 + 32 * mt + 16 * h) = pk;
+      }
+    }
+  }
+}
+
+// ops k_dense2 takes: tap-major dense convs ('same' padding, stride 1) with the plain epilogue and no residual panes
+bool dense2_takes(const SepP& p) {
+  const EpiP& e = p.e;
+  if (p.gen != 2 || p.dense_k <= 1 || p.K != 0 || p.n_panes != 0 || p.cin_pad % DENSE2_CK || p.cin > p.cin_pad) return false;
+  if (e.flags & (QASR_F_LOGITS | QASR_F_RESADD)) return false;
+  if (e.n_outs < 1 || e.n_outs > QASR_MAX_OUTS || e.Tp % 64 || e.T > e.Tp) return false;
+  for (int j = 0; j < e.n_outs; ++j)
+    if (e.outs[j].mode != 1 || !e.outs[j].mtab || !e.outs[j].ptr) return false;
+  if (((p.dense_k - 1) * p.dilation) & 1) return false;
+  const int pad = p.dilation * (p.dense_k - 1) / 2, halo = (pad + 15) & ~15;
+  return halo <= 32;                                         // rows <= 32 MT + 64 (dense2_stage's task count); 46 KB of LDS at most
+}
+
+static int dense2_mt(const SepP& p) { return p.e.Tp >= 256 ? 8 : p.e.Tp / 32; }   // Tp is a multiple of 64: 2, 4, 6 or 8 tiles
+
+void dense2_label(const SepP& p, char* buf, size_t cap) {
+  snprintf(buf, cap, "k_dense2<%d, %s>", dense2_mt(p), p.e.acc_dbg ? "true" : "false");
+}
+
+template <int MT, bool DBG>
+static int launch_dense2_v(hipStream_t s, const SepP& p) {
+  const int pad = p.dilation * (p.dense_k - 1) / 2, halo = (pad + 15) & ~15;
+  const size_t smem = (size_t)(32 * MT + 2 * halo) * DENSE2_XP;
+  if (!p.x || !p.w || !p.bias || !p.e.lens || p.e.B < 1 || p.e.cout < 1 || smem > 160 * 1024) return QASR_ERR_ARG;
+  static int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (attr_dev != dev) {
+    (void)hipFuncSetAttribute((const void*)k_dense2<MT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_dev = dev;
+  }
+  const int tt = 32 * MT;
+  dim3 g(p.e.B, ((p.e.cout + 127) & ~127) / 128, (p.e.Tp + tt - 1) / tt);
+  hipLaunchKernelGGL((k_dense2<MT, DBG>), g, dim3(DENSE2_NT), smem, s, p);
+  return QASR_OK;
+}
+
+int launch_dense2(hipStream_t s, const SepP& p) {
+  const bool dbg = p.e.acc_dbg != nullptr;
+  switch (dense2_mt(p)) {
+    case 2: return dbg ? launch_dense2_v<2, true>(s, p) : launch_dense2_v<2, false>(s, p);
+    case 4: return dbg ? launch_dense2_v<4, true>(s, p) : launch_dense2_v<4, false>(s, p);
+    case 6: return dbg ? launch_dense2_v<6, true>(s, p) : launch_dense2_v<6, false>(s, p);
+    case 8: return dbg ? launch_dense2_v<8, true>(s, p) : launch_dense2_v<8, false>(s, p);
+    default: return QASR_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace qasr

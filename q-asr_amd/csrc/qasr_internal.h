@@ -102,6 +102,11 @@ int sep2_mega_shape(const SepP& p);                    // >= 0: the persistent k
 size_t sep2_mega_smem(const SepP& p);
 int launch_sep2_mega(hipStream_t s, const MegaOp* dev_ops, int n_ops, int B, size_t smem);
 
+// qasr_dense2.hip: Jasper's plain dense convs (no residual panes) on 128-channel x 256-frame work-groups
+bool dense2_takes(const SepP& p);
+int launch_dense2(hipStream_t s, const SepP& p);
+void dense2_label(const SepP& p, char* buf, size_t cap);
+
 extern long long* g_prof;
 extern int g_prof_mode;
 extern int g_prof_cap;      // timeline mode: work-groups the buffer holds (4 int64 each)

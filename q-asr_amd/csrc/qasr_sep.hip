@@ -42,6 +42,10 @@ bool sep_supported(int K, int dilation) {
 // template arguments of the k_sep instantiation launch_sep picks for `p` (as rocprofv3 prints them)
 void sep_kernel_label(const SepP& p, char* buf, size_t cap) {
   const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
+  if (dense2_takes(p)) {
+    dense2_label(p, buf, cap);
+    return;
+  }
   if (sep2_takes(p)) {
     snprintf(buf, cap, "k_sep2<%d, %d, %d, %d, %s, %d>", p.K, p.cin_pad >> 7, (p.e.flags & QASR_F_RESADD) ? p.panes[0].cin_pad >> 7 : 0,
              (p.e.cout + 255) / 256, dbg ? "true" : "false", sep2_tile(p));
@@ -61,6 +65,7 @@ int sep_tile_for(const SepP& p) {
 
 int launch_sep(hipStream_t s, const SepP& p) {
   const bool dbg = p.e.acc_dbg || p.dw_acc_dbg;
+  if (dense2_takes(p)) return launch_dense2(s, p);           // Jasper's plain dense convs (qasr_dense2.hip)
   if (sep2_takes(p)) {
     const int tt = sep2_tile(p);
     if (tt == 128) return dbg ? launch_sep2_inst<128, true>(s, p) : launch_sep2_inst<128, false>(s, p);

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), 'csrc')
 LIB = os.path.join(HERE, 'libqasr_hip.so')
 SOURCES = ['qasr_kernels.hip', 'qasr_sep.hip', 'qasr_sep_t32.hip', 'qasr_sep_t32_dbg.hip', 'qasr_sep_t64.hip',
-           'qasr_sep_t64_dbg.hip', 'qasr_sep_t128.hip', 'qasr_sep2_t32.hip', 'qasr_sep2_t32_dbg.hip', 'qasr_sep2_t64.hip', 'qasr_sep2_t64_dbg.hip', 'qasr_sep2_t128.hip', 'qasr_sep2_t128_dbg.hip', 'qasr_sep2_mega.hip',
+           'qasr_sep_t64_dbg.hip', 'qasr_sep_t128.hip', 'qasr_sep2_t32.hip', 'qasr_sep2_t32_dbg.hip', 'qasr_sep2_t64.hip', 'qasr_sep2_t64_dbg.hip', 'qasr_sep2_t128.hip', 'qasr_sep2_t128_dbg.hip', 'qasr_sep2_mega.hip', 'qasr_dense2.hip',
            'qasr_utt.hip', 'qasr_engine.hip', 'qasr_frontend.hip', 'qasr_calib.hip', 'qasr_dynamic.hip', 'qasr_decoder.hip', 'qasr_stem.hip']
 
 
