@@ -68,7 +68,10 @@ __device__ __forceinline__ void dense2_stage(lds_u8* Xs, const int8_t* __restric
   }
 }
 
-template <int MT, bool DBG>
+// RES: block-end layers (jasper.py:664-682) - after the main conv, every residual pane (a 1x1 conv of an earlier block's
+// output, dense residual: up to 10 of them) is multiplied in the same work-group and added with res_act's clamp after
+// every add; 128 frames per work-group (MT = 4: main and pane accumulators side by side)
+template <int MT, bool DBG, bool RES>
 __global__ void __launch_bounds__(DENSE2_NT, 2) k_dense2(SepP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   lds_u8* const Xs = (lds_u8*)smem;
@@ -94,7 +97,7 @@ __global__ void __launch_bounds__(DENSE2_NT, 2) k_dense2(SepP p) {
   const float sb = f_exact ? e.sb[co] : 1.0f;
   double Mo[QASR_MAX_OUTS];
 #pragma unroll
-  for (int j = 0; j < QASR_MAX_OUTS; ++j) Mo[j] = j < n_outs ? e.outs[j].mtab[co] : 0.0;
+  for (int j = 0; j < QASR_MAX_OUTS; ++j) Mo[j] = (!RES && j < n_outs) ? e.outs[j].mtab[co] : 0.0;
 
   v16i acc[MT];
 #pragma unroll
@@ -165,6 +168,113 @@ __global__ void __launch_bounds__(DENSE2_NT, 2) k_dense2(SepP p) {
         if (t < eT) e.acc_dbg[((size_t)b * ecout + co) * eTp + t] = acc[mt][r];
       }
   }
+  auto any_wide = [&](const v16i& v) {
+    int mx = v[0], mn = v[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) { mx = max(mx, v[r]); mn = min(mn, v[r]); }
+    return __any(mx >= (1 << 21) || mn < -(1 << 21)) != 0;
+  };
+  // 16 codes of a lane (MFMA C layout) -> 16 consecutive frames per lane -> one masked 16-byte store
+  auto store16 = [&](void* optr, int mt, const int (&q)[16]) {
+    unsigned P[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) P[g] = pack4b(q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3]);
+    const auto s02 = __builtin_amdgcn_permlane32_swap(P[0], P[2], false, false);
+    const auto s13 = __builtin_amdgcn_permlane32_swap(P[1], P[3], false, false);
+    v4i pk = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+    if (t0 + 32 * (mt + 1) > lim) pk = sep2_mask16(pk, lim - (t0 + 32 * mt + 16 * h));   // masked frames (uniform branch)
+    if (co < ecout) *(v4i*)((int8_t*)optr + ((size_t)b * ecout + co) * eTp + t0 + 32 * mt + 16 * h) = pk;
+  };
+  if constexpr (RES) {
+    // res_act (jasper.py:680-682; quant_utils.py:187-214): d = rint(z_main M_main); per pane d = clamp(d + rint(z_pane M_pane)),
+    // the clamp after EVERY add; then ReLU and the consumers' QuantAct.  Every |z M| < 2^30 (the packer flags the others
+    // QASR_F_WIDE_RQ and they stay on k_sep): the rounded products come out of the low mantissa word, the sum is an integer
+    const int qlo = e.qlo, qhi = e.qhi;
+    {
+      const double Mm = e.m_main[co];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bool wide = f_exact && any_wide(acc[mt]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = rq_rint(wide ? z_roundtrip(acc[mt][r], sb, false) : acc[mt][r], Mm);
+      }
+    }
+    for (int pi = 0; pi < p.n_panes; ++pi) {
+      const PaneP& pn = p.panes[pi];
+      const int pcin_pad = pn.cin_pad;
+      const unsigned rflip = pn.x_unsigned ? 0x80808080u : 0u;
+      const int pbias = pn.bias[co];
+      const double Mp = pn.m[co];
+      const float sbp = f_exact ? pn.sb[co] : 1.0f;
+      v16i accp[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accp[mt][r] = pbias;
+      for (int c = 0; c < pcin_pad / DENSE2_CK; ++c) {
+        v4i wq[4];                                           // requested in front of the staging: its latency runs under it
+        {
+          const v4i* wp = w_frag(pn.w, pcin_pad, co_row, 4 * c);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) wq[k] = wp[64 * k];
+        }
+        __syncthreads();                                     // every wave has read the previous image
+        dense2_stage<MT>(Xs, pn.x, pn.cin, eTp, b, DENSE2_CK * c, t0, 32 * MT, rflip);
+        __syncthreads();
+        v4i ap[2][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ap[0][mt] = *(const lds_v4i*)(a_lane + 32 * mt * DENSE2_XP);
+        __builtin_amdgcn_sched_barrier(0);
+        sep2_for<0, 4>([&](auto ksc) {
+          constexpr int ks = decltype(ksc)::value;
+          sep2_for<0, MT>([&](auto mtc) {
+            constexpr int mt = decltype(mtc)::value;
+            accp[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ap[ks & 1][mt], wq[ks], accp[mt], 0, 0, 0);
+            if constexpr (ks + 1 < 4) ap[(ks + 1) & 1][mt] = *(const lds_v4i*)(a_lane + 32 * mt * DENSE2_XP + 32 * (ks + 1));
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        });
+      }
+      if (DBG && pn.acc_dbg && co < ecout) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int t = t0 + 32 * mt + mfma32_row(r, h);
+            if (t < eT) pn.acc_dbg[((size_t)b * ecout + co) * eTp + t] = accp[mt][r];
+          }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bool wide = f_exact && any_wide(accp[mt]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc[mt][r] = med3i(acc[mt][r] + rq_rint(wide ? z_roundtrip(accp[mt][r], sbp, false) : accp[mt][r], Mp), qlo, qhi);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (t0 + 32 * mt >= eTp) continue;
+      int z[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = f_relu ? max(acc[mt][r], 0) : acc[mt][r];
+#pragma unroll 1
+      for (int j = 0; j < n_outs; ++j) {
+        const OutP& o = e.outs[j];
+        if (o.mode == 2) {
+          store16(o.ptr, mt, z);
+        } else {                                             // mode 0: scalar multiplier towards the consumer's QuantAct
+          const double Ms = o.m;
+          const int olo = o.lo, ohi = o.hi;
+          int q[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) q[r] = requant_clamp(z[r], Ms, olo, ohi);
+          store16(o.ptr, mt, q);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     if (t0 + 32 * mt >= eTp) continue;                       // (last time tile of a long utterance; uniform)
@@ -199,26 +309,49 @@ __global__ void __launch_bounds__(DENSE2_NT, 2) k_dense2(SepP p) {
   }
 }
 
-// ops k_dense2 takes: tap-major dense convs ('same' padding, stride 1) with the plain epilogue and no residual panes
-bool dense2_takes(const SepP& p) {
+// ops k_dense2 takes: tap-major dense convs ('same' padding, stride 1) with the plain epilogue, or with residual panes and
+// res_act (Jasper's block ends)
+static bool dense2_common(const SepP& p) {
   const EpiP& e = p.e;
-  if (p.gen != 2 || p.dense_k <= 1 || p.K != 0 || p.n_panes != 0 || p.cin_pad % DENSE2_CK || p.cin > p.cin_pad) return false;
-  if (e.flags & (QASR_F_LOGITS | QASR_F_RESADD)) return false;
+  if (p.gen != 2 || p.dense_k <= 1 || p.K != 0 || p.cin_pad % DENSE2_CK || p.cin > p.cin_pad) return false;
+  if (e.flags & QASR_F_LOGITS) return false;
   if (e.n_outs < 1 || e.n_outs > QASR_MAX_OUTS || e.Tp % 64 || e.T > e.Tp) return false;
-  for (int j = 0; j < e.n_outs; ++j)
-    if (e.outs[j].mode != 1 || !e.outs[j].mtab || !e.outs[j].ptr) return false;
   if (((p.dense_k - 1) * p.dilation) & 1) return false;
   const int pad = p.dilation * (p.dense_k - 1) / 2, halo = (pad + 15) & ~15;
   return halo <= 32;                                         // rows <= 32 MT + 64 (dense2_stage's task count); 46 KB of LDS at most
 }
+static bool dense2_res(const SepP& p) {
+  const EpiP& e = p.e;
+  if (!(e.flags & QASR_F_RESADD) || (e.flags & QASR_F_WIDE_RQ) || p.n_panes < 1 || p.n_panes > QASR_MAX_PANES || !e.m_main) return false;
+  for (int k = 0; k < p.n_panes; ++k)
+    if (!p.panes[k].x || !p.panes[k].w || !p.panes[k].bias || !p.panes[k].m || p.panes[k].cin_pad % DENSE2_CK ||
+        p.panes[k].cin > p.panes[k].cin_pad || ((e.flags & QASR_F_EXACT_Z) && !p.panes[k].sb))
+      return false;
+  for (int j = 0; j < e.n_outs; ++j)
+    if ((e.outs[j].mode != 0 && e.outs[j].mode != 2) || !e.outs[j].ptr) return false;
+  return true;
+}
+static bool dense2_plain(const SepP& p) {
+  const EpiP& e = p.e;
+  if ((e.flags & QASR_F_RESADD) || p.n_panes != 0) return false;
+  for (int j = 0; j < e.n_outs; ++j)
+    if (e.outs[j].mode != 1 || !e.outs[j].mtab || !e.outs[j].ptr) return false;
+  return true;
+}
+bool dense2_takes(const SepP& p) { return dense2_common(p) && (dense2_plain(p) || dense2_res(p)); }
 
-static int dense2_mt(const SepP& p) { return p.e.Tp >= 256 ? 8 : p.e.Tp / 32; }   // Tp is a multiple of 64: 2, 4, 6 or 8 tiles
-
-void dense2_label(const SepP& p, char* buf, size_t cap) {
-  snprintf(buf, cap, "k_dense2<%d, %s>", dense2_mt(p), p.e.acc_dbg ? "true" : "false");
+// frame tiles per wave: the plain form takes up to 8 (Tp is a multiple of 64: 2, 4, 6 or 8), the block-end form 4 (2 for Tp = 64)
+static int dense2_mt(const SepP& p) {
+  if (p.e.flags & QASR_F_RESADD) return p.e.Tp >= 128 ? 4 : 2;
+  return p.e.Tp >= 256 ? 8 : p.e.Tp / 32;
 }
 
-template <int MT, bool DBG>
+void dense2_label(const SepP& p, char* buf, size_t cap) {
+  const bool dbg = p.e.acc_dbg != nullptr;
+  snprintf(buf, cap, "k_dense2<%d, %s, %s>", dense2_mt(p), dbg ? "true" : "false", (p.e.flags & QASR_F_RESADD) ? "true" : "false");
+}
+
+template <int MT, bool DBG, bool RES>
 static int launch_dense2_v(hipStream_t s, const SepP& p) {
   const int pad = p.dilation * (p.dense_k - 1) / 2, halo = (pad + 15) & ~15;
   const size_t smem = (size_t)(32 * MT + 2 * halo) * DENSE2_XP;
@@ -227,22 +360,26 @@ static int launch_dense2_v(hipStream_t s, const SepP& p) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (attr_dev != dev) {
-    (void)hipFuncSetAttribute((const void*)k_dense2<MT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_dense2<MT, DBG, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_dev = dev;
   }
   const int tt = 32 * MT;
   dim3 g(p.e.B, ((p.e.cout + 127) & ~127) / 128, (p.e.Tp + tt - 1) / tt);
-  hipLaunchKernelGGL((k_dense2<MT, DBG>), g, dim3(DENSE2_NT), smem, s, p);
+  hipLaunchKernelGGL((k_dense2<MT, DBG, RES>), g, dim3(DENSE2_NT), smem, s, p);
   return QASR_OK;
 }
 
 int launch_dense2(hipStream_t s, const SepP& p) {
   const bool dbg = p.e.acc_dbg != nullptr;
+  if (p.e.flags & QASR_F_RESADD) {
+    if (dense2_mt(p) == 4) return dbg ? launch_dense2_v<4, true, true>(s, p) : launch_dense2_v<4, false, true>(s, p);
+    return dbg ? launch_dense2_v<2, true, true>(s, p) : launch_dense2_v<2, false, true>(s, p);
+  }
   switch (dense2_mt(p)) {
-    case 2: return dbg ? launch_dense2_v<2, true>(s, p) : launch_dense2_v<2, false>(s, p);
-    case 4: return dbg ? launch_dense2_v<4, true>(s, p) : launch_dense2_v<4, false>(s, p);
-    case 6: return dbg ? launch_dense2_v<6, true>(s, p) : launch_dense2_v<6, false>(s, p);
-    case 8: return dbg ? launch_dense2_v<8, true>(s, p) : launch_dense2_v<8, false>(s, p);
+    case 2: return dbg ? launch_dense2_v<2, true, false>(s, p) : launch_dense2_v<2, false, false>(s, p);
+    case 4: return dbg ? launch_dense2_v<4, true, false>(s, p) : launch_dense2_v<4, false, false>(s, p);
+    case 6: return dbg ? launch_dense2_v<6, true, false>(s, p) : launch_dense2_v<6, false, false>(s, p);
+    case 8: return dbg ? launch_dense2_v<8, true, false>(s, p) : launch_dense2_v<8, false, false>(s, p);
     default: return QASR_ERR_UNSUPPORTED;
   }
 }
