@@ -512,7 +512,9 @@ def run(args):
                    'log_probs': 'not written in the timed step (tokens and encoded lengths are; the reference forward also returns '
                                 'log-probs: 0.9 MB of stores per step, want_logp=False here)',
                    'hip_graph': not args.no_graph,
-                   'kernels': 'k_utt' if args.whole_utterance else f'k_sep2 / k_sep, {tile}-frame tiles' + (' (64 where a layer has residual panes)' if tile == 128 else ''),
+                   'kernels': ('k_utt' if args.whole_utterance else
+                               'k_dense2 (128 output channels x 256 / 128 frames per work-group), k_dense, k_sep' if args.config == 'jasper' else
+                               f'k_sep2 ({tile}-frame tiles), k_stem, k_dec, k_sep (block 16)') + (', persistent launch' if args.persistent else ''),
                    'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + token gather' if world > 1 else ''),
                    'wer': 'not measurable here: no LibriSpeech / checkpoint in the image'},
     }
