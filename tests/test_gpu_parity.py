@@ -280,6 +280,48 @@ def test_long_utterances_tile_sizes_agree(eng, golden_dir):
                 assert np.array_equal(a, b_), fam
 
 
+def test_jasper_long_utterances_dense2_against_oracle_and_k_sep(eng, golden_dir):
+    """k_dense2 beyond one 256-frame work-group (grid.z > 1, the last time tile partial), frame counts that are not a
+    multiple of 64, ragged lengths: (a) the mini Jasper (dense residual, panes) against OracleNet on 700 / 333-frame
+    utterances - tokens, lengths, log-probs; (b) Jasper10x5dr at 2 x 1101 frames (551 encoder frames: three time tiles for the
+    plain layers, five for the block ends): k_dense2 (kernel generation 2) and round 1's k_sep (generation 1) give identical
+    log-probs, tokens and lengths, and the labels say which ran."""
+    d, meta = _load(golden_dir, 'net_minij_w8a8')
+    cfg = topology.mini_jasper()
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    blob, _ = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    net = O.OracleNet(topology.conv_plan(cfg), cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    for T, ls in ((700, [700, 333, 5]), (333, [333, 130])):
+        x = synth.make_features(len(ls), cfg.feat_in, T, 29 + T)
+        want = net.forward(x, ls)
+        e = eng.Engine(blob, 0)
+        lp, tk, el = e.forward(torch.from_numpy(x).cuda(), torch.tensor(ls))
+        assert any(l.startswith('k_dense2<') and l.endswith('true>') for l in e.op_labels()) and \
+            any(l.startswith('k_dense2<') and l.endswith('false>') for l in e.op_labels()), e.op_labels()
+        assert np.array_equal(el.cpu().numpy(), want['enc_len'])
+        for b in range(len(ls)):
+            n = int(want['enc_len'][b])
+            assert np.array_equal(tk.cpu().numpy()[b, :n], want['tokens'][b, :n]), (T, b)
+            np.testing.assert_allclose(lp.cpu().numpy()[b, :n], want['log_probs'][b, :n], rtol=1e-4, atol=5e-5)
+        e.close()
+    d, meta = _load(golden_dir, 'net_jasper_w8a8')
+    cfg = topology.jasper10x5dr()
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    blob, _ = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    x = torch.from_numpy(synth.make_features(2, 64, 1101, 31)).cuda()
+    lens = torch.tensor([1101, 642])
+    outs = []
+    for gen in (2, 1):
+        e = eng.Engine(blob, 0, sep_gen=gen, tile=128)
+        lp, tk, el = e.forward(x, lens)
+        labels = e.op_labels()
+        assert (sum(l.startswith('k_dense2<') for l in labels) >= 50) == (gen == 2), labels
+        outs.append((lp.cpu().numpy(), tk.cpu().numpy(), el.cpu().numpy()))
+        e.close()
+    for a, b_ in zip(*outs):
+        assert np.array_equal(a, b_)
+
+
 def test_steps_in_flight_match_serial(eng, golden_dir):
     """bench.py keeps several steps in flight (one engine + HIP stream each): kernels of different steps interleave on
     the CUs, which exposes any tensor whose arena slot is recycled before its last reader (the halo reads of a fused
