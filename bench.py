@@ -139,15 +139,19 @@ def pmc_traffic():
     fs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_FETCH_SIZE.txt')), key=tag)
     if not fs:
         return out, src
-    src = os.path.basename(fs[-1]).replace('_pmc_FETCH_SIZE.txt', '')
-    for name, mult in (('FETCH_SIZE', 2.0), ('WRITE_SIZE', 1.0)):
-        path = os.path.join(ROOT, 'profiles', f'{src}_pmc_{name}.txt')
-        if not os.path.exists(path):
-            return {}, None
-        for line in open(path):
-            m = re.match(r'\s*(?:void )?qasr::(.+?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$', line)
-            if m:
-                out[m.group(1)] = out.get(m.group(1), 0.0) + mult * 1024.0 * float(m.group(4))
+    rnd, ver = tag(fs[-1])
+    # every summary of the newest (round, version): one per configuration (r03_v2_*, r03_v2_jasper_*), different kernels
+    srcs = [os.path.basename(f).replace('_pmc_FETCH_SIZE.txt', '') for f in fs if tag(f) == (rnd, ver)]
+    src = ' + '.join(srcs)
+    for one in srcs:
+        for name, mult in (('FETCH_SIZE', 2.0), ('WRITE_SIZE', 1.0)):
+            path = os.path.join(ROOT, 'profiles', f'{one}_pmc_{name}.txt')
+            if not os.path.exists(path):
+                continue
+            for line in open(path):
+                m = re.match(r'\s*(?:void )?qasr::(.+?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$', line)
+                if m:
+                    out[m.group(1)] = out.get(m.group(1), 0.0) + mult * 1024.0 * float(m.group(4))
     return out, src
 
 

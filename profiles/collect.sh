@@ -5,16 +5,17 @@
 # usage: bash profiles/collect.sh <tag>
 set -o pipefail
 TAG=${1:-rXX}
+EXTRA=${2:-}                     # e.g. "--config jasper"
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --steps 50 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
+python3 $R/bench.py $EXTRA --steps 50 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 # kernel durations: one step in flight (what bench.py's HIP-event roofline pass measures), then the default 4 in flight
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o p -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --streams 1 --tile 128 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_rocprof.err || exit 2
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof4_$TAG -o p -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof_4inflight.json 2>> $OUT/${TAG}_rocprof.err || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o p -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --streams 1 --tile 128 $EXTRA > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_rocprof.err || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof4_$TAG -o p -- python3 $R/bench.py $EXTRA --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof_4inflight.json 2>> $OUT/${TAG}_rocprof.err || exit 2
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_${TAG}_$C -o c -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --streams 1 --tile 128 > $OUT/pmc_${TAG}_$C.log 2>&1 || exit 3
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_${TAG}_$C -o c -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --streams 1 --tile 128 $EXTRA > $OUT/pmc_${TAG}_$C.log 2>&1 || exit 3
 done
 python3 - "$TAG" "$OUT" <<'PY'
 import collections, csv, glob, os, sys
