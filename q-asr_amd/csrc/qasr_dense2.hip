@@ -79,6 +79,15 @@ __global__ void __launch_bounds__(DENSE2_NT, 2) k_dense2(SepP p) {
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x, t0 = blockIdx.z * (32 * MT);
+  // diagnostics (qasr_debug_timeline): every work-group stamps start / end (100 MHz) and its shader cycles: the clock the
+  // chip holds under this kernel = cycles / (end - start) x 100 MHz
+  const int wg_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const bool tline = p.prof && (p.prof_mode & 255) == 1 && tid == 0 && wg_id < p.prof_cap;
+  long long tl_start = 0, tl_clk = 0;
+  if (tline) {
+    tl_start = (long long)__builtin_amdgcn_s_memrealtime();
+    tl_clk = (long long)__builtin_amdgcn_s_memtime();
+  }
   const int co_row = 128 * blockIdx.y + 32 * wave;           // this wave's 32 output channels (cout_pad is a multiple of 128)
   const int co = co_row + r31;                               // MFMA C layout: channel = lane & 31
   const int K = p.dense_k, dil = p.dilation, pad = dil * (K - 1) / 2;
@@ -273,6 +282,11 @@ __global__ void __launch_bounds__(DENSE2_NT, 2) k_dense2(SepP p) {
         }
       }
     }
+    if (tline) {
+      long long* r = p.prof + 4 * (size_t)wg_id;
+      r[0] = tl_start; r[1] = (long long)__builtin_amdgcn_s_memrealtime(); r[2] = 0;
+      r[3] = (long long)__builtin_amdgcn_s_memtime() - tl_clk;
+    }
     return;
   }
 #pragma unroll
@@ -306,6 +320,11 @@ __global__ void __launch_bounds__(DENSE2_NT, 2) k_dense2(SepP p) {
         if (co < ecout) *(v4i*)((int8_t*)o.ptr + ((size_t)b * ecout + co) * eTp + t0 + 32 * mt + 16 * h) = pk;
       }
     }
+  }
+  if (tline) {
+    long long* r = p.prof + 4 * (size_t)wg_id;
+    r[0] = tl_start; r[1] = (long long)__builtin_amdgcn_s_memrealtime(); r[2] = 0;
+    r[3] = (long long)__builtin_amdgcn_s_memtime() - tl_clk;
   }
 }
 
@@ -365,7 +384,11 @@ static int launch_dense2_v(hipStream_t s, const SepP& p) {
   }
   const int tt = 32 * MT;
   dim3 g(p.e.B, ((p.e.cout + 127) & ~127) / 128, (p.e.Tp + tt - 1) / tt);
-  hipLaunchKernelGGL((k_dense2<MT, DBG, RES>), g, dim3(DENSE2_NT), smem, s, p);
+  SepP q = p;
+  q.prof = g_prof_mode == 1 ? g_prof : nullptr;
+  q.prof_mode = g_prof_mode;
+  q.prof_cap = g_prof_cap;
+  hipLaunchKernelGGL((k_dense2<MT, DBG, RES>), g, dim3(DENSE2_NT), smem, s, q);
   return QASR_OK;
 }
 
