@@ -274,7 +274,35 @@ def in_flight_timing(lane, roof, ops, reps=20):
     torch.cuda.synchronize()
     ms = max(ev[k][0].elapsed_time(ev[k][1]) for k in range(S))
     t = ms * 1e-3 / (S * reps * len(ops))                        # s per launch, all streams' launches counted
-    return {'launches_in_flight': S, 'effective_launch_us': 1e6 * t,
+    # the clock the chip holds meanwhile: every work-group of the kernel stamps its start / end (100 MHz s_memrealtime) and its
+    # shader cycles (s_memtime) into a diagnostic buffer (qasr_debug_timeline; the timed launches above run without it)
+    clock = None
+    try:
+        import ctypes as C
+        import numpy as np
+        lib = lane['engs'][0].lib
+        buf = torch.zeros(4 * 16384, dtype=torch.int64, device='cuda')
+        lib.qasr_debug_timeline(C.c_void_p(buf.data_ptr()), buf.numel() // 4)
+        for _ in range(3):
+            for o in ops:
+                for k in range(S):
+                    lane['engs'][k].run_op(o, stream=lane['streams'][k])
+        torch.cuda.synchronize()
+        lib.qasr_debug_timeline(C.c_void_p(0), 0)
+        st = buf.cpu().numpy().reshape(-1, 4)
+        st = st[(st[:, 1] > st[:, 0]) & (st[:, 3] > 0)]
+        if len(st):
+            clock = float(np.median(st[:, 3] / ((st[:, 1] - st[:, 0]) * 10.0)))      # cycles / ns = GHz
+    except Exception as exc:                                     # diagnostics only
+        log(f'clock probe skipped: {exc}')
+    extra = {}
+    if clock:
+        peak_at_clock = PEAK_INT8_OPS * clock / 2.4
+        extra = {'sustained_clock_ghz': clock,
+                 'mfma_frac_at_sustained_clock': (roof['mfma_ops_per_launch'] + roof['depthwise_ops_per_launch']) / t / peak_at_clock,
+                 'clock_note': 'median over the work-groups of the kernel of shader cycles / elapsed 100 MHz ticks with the S launches in '
+                               'flight; `peak` (and every *_frac) is quoted at 2.4 GHz, the chip holds less under load'}
+    return {**extra, 'launches_in_flight': S, 'effective_launch_us': 1e6 * t,
             'stream_launch_us': 1e3 * ms / (reps * len(ops)),
             'achieved_gb_s': roof['algorithmic_bytes_per_launch'] / t / 1e9,
             'hbm_frac': roof['algorithmic_bytes_per_launch'] / t / PEAK_HBM,
