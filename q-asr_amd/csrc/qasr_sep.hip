@@ -29,6 +29,7 @@ bool sep2_takes(const SepP& p) { return p.gen == 2 && sep2_shape_ok(p); }
 // qasr_engine_opts.res_tile128 = 0 keeps them on 64 (the engine then hands those ops over with tile = 64)
 static int sep2_tile(const SepP& p) {
   if (p.tile == 128) return (p.K > 0 && p.e.Tp % 128 == 0) ? 128 : 64;
+  if (p.K > 0 && p.dilation == 2) return 64;                 // the dilation-2 form has no 32-frame instantiation (16 samples per parity)
   return p.tile == 64 ? 64 : 32;
 }
 
@@ -47,8 +48,8 @@ void sep_kernel_label(const SepP& p, char* buf, size_t cap) {
     return;
   }
   if (sep2_takes(p)) {
-    snprintf(buf, cap, "k_sep2<%d, %d, %d, %d, %s, %d>", p.K, p.cin_pad >> 7, (p.e.flags & QASR_F_RESADD) ? p.panes[0].cin_pad >> 7 : 0,
-             (p.e.cout + 255) / 256, dbg ? "true" : "false", sep2_tile(p));
+    snprintf(buf, cap, p.K > 0 && p.dilation == 2 ? "k_sep2<%d, %d, %d, %d, %s, %d, 2>" : "k_sep2<%d, %d, %d, %d, %s, %d>", p.K, p.cin_pad >> 7,
+             (p.e.flags & QASR_F_RESADD) ? p.panes[0].cin_pad >> 7 : 0, (p.e.cout + 255) / 256, dbg ? "true" : "false", sep2_tile(p));
     return;
   }
   snprintf(buf, cap, "k_sep<%d, %d, %d, %s, %d>", p.K, p.K > 0 ? p.dilation : 1, sep_epilogue_class(p), dbg ? "true" : "false",

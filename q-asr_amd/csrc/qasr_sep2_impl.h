@@ -259,14 +259,26 @@ struct Sep2PassP {
 // The work of ONE work-group: utterance b, frames [t0, t0 + TT), every channel.  k_sep2 below runs it once per work-group
 // of a (B, Tp / TT) grid; the persistent kernel (qasr_sep2_mega.hip) walks layers and time tiles with it.  `p` may live
 // in the kernel-argument segment or in global memory: its address is wave-uniform either way (scalar loads).
-template <int K, int NG, int NGP, int NP, bool DBG, int TT>
+// DIL = 2 (QuartzNet's block 16, k = 87): out[t] = sum_m w[m] x[t - 86 + 2 m] only touches frames of t's parity, so every
+// channel is staged as TWO rows - its even and its odd frames - and each row sees an ordinary dilation-1 conv over TT / 2
+// samples with the same taps: a depthwise group is 8 real channels x 2 parities per wave (16 MFMA blocks as ever), the
+// geometry is Sep2Geo<K, TT / 2>, and the requantised values go to the [channel][frame] image byte by byte (a lane's four
+// values are frames of one parity, two apart).  Everything behind the depthwise stage is unchanged.
+template <int K, int NG, int NGP, int NP, bool DBG, int TT, int DIL = 1>
 __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int t0, const bool stamp_wg, const int wg_id) {
-  using G = Sep2Geo<K, TT>;
+  using G = Sep2Geo<K, TT / DIL>;
   constexpr bool RES = NGP > 0;
+  static_assert(DIL == 1 || (DIL == 2 && !RES && TT >= 64), "dilation 2: plain layers, 64- / 128-frame tiles");
   constexpr int MT = TT / 32;
   constexpr int NU = G::NU, S = G::S, NS = G::NS;
   constexpr int CIN_PAD = 128 * NG, PCIN_PAD = 128 * NGP;
-  constexpr int NCHUNK = (CIN_PAD + SEP2_CH - 1) / SEP2_CH;
+  constexpr int RCH = 16 / DIL, GCH = SEP2_CH / DIL;         // real channels per wave / per work-group in one depthwise group
+  constexpr int NCHUNK = (CIN_PAD + GCH - 1) / GCH;
+  // staging granules of a wave and group: DIL 1: 16 rows x NPG granules of the row itself; DIL 2: RCH real channels x the
+  // granules of the REAL window [t0 - 2 HALO, t0 + TT + 2 HALO) (each splits into 8 even + 8 odd bytes); tap rows: RCH x KS bytes
+  constexpr int NPGR = DIL == 1 ? G::NPG : (TT + 2 * DIL * G::HALO) / 16;
+  constexpr int NPT = (RCH * NPGR + 63) / 64, NTG = RCH * G::KS / 16, NTT = (NTG + 63) / 64;
+  static_assert(DIL == 1 || (8 * NPGR == G::WLEN && (RCH * G::KS) % 16 == 0), "dilation 2: window / tap granules");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const EpiP& e = p.e;
   int tid_ = threadIdx.x;
@@ -315,37 +327,38 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
   // the depthwise math (pf<CH>(lo, hi)).
   const unsigned flip = p.x_unsigned ? 0x80808080u : 0u;
   constexpr int NRT = RES ? (TT * PCIN_PAD / 16) / SEP2_NT : 0;
-  v4i pc[G::NPT], pt[G::NTT], rr[NRT > 0 ? NRT : 1], wf[16];
+  v4i pc[NPT], pt[NTT], rr[NRT > 0 ? NRT : 1], wf[16];
   const int co_l = 32 * wave + (lane & 31);                  // row inside a 256-channel pass
   const v4i* const w0 = w_frag(p.w, CIN_PAD, co_l, 0);
   // window + tap rows of this wave's 16 channels of group g (channels 128 g + 16 wave ..): 16-B granules, lane-contiguous.
   // Everything per lane is the same for every group and computed once - byte offsets of its granules from the group's
   // (wave-uniform) row 0, zero-padding masks, LDS addresses: a group's staging is loads, one bit-op per dword, stores
-  int woff[G::NPT], toff[G::NTT];
-  unsigned wkeep[G::NPT];
-  lds_u8* wlds[G::NPT];
+  int woff[NPT], toff[NTT];
+  unsigned wkeep[NPT];
+  lds_u8* wlds[NPT];
 #pragma unroll
-  for (int i = 0; i < G::NPT; ++i) {
+  for (int i = 0; i < NPT; ++i) {
     const int pi = lane + 64 * i;
-    const int row = pi / G::NPG, col = pi - row * G::NPG;
-    const int t = t0 - G::HALO + 16 * col;                   // a granule lies entirely inside or outside [0, Tp)
+    const int row = pi / NPGR, col = pi - row * NPGR;
+    const int t = t0 - DIL * G::HALO + 16 * col;             // a granule lies entirely inside or outside [0, Tp)
     // unconditional loads from clamped addresses (the keep mask zeroes what lies outside): a load under a branch with a
     // zero-initialised destination is waited for on the spot
-    woff[i] = min(row, 15) * eTp + min(max(t, 0), eTp - 16);
+    woff[i] = min(row, RCH - 1) * eTp + min(max(t, 0), eTp - 16);
     wkeep[i] = (t >= 0 && t < eTp) ? 0xffffffffu : 0u;       // conv zero padding beyond the tensor
-    wlds[i] = Wsw + min(row, 15) * G::WP + 16 * col;
+    // DIL 2: the granule's even bytes go to row 2 r (8 bytes at 8 col), its odd bytes to row 2 r + 1
+    wlds[i] = DIL == 1 ? Wsw + min(row, 15) * G::WP + 16 * col : Wsw + 2 * min(row, RCH - 1) * G::WP + 8 * col;
     asm volatile("" : "+v"(wkeep[i]));                       // a mask, not a predicate: (v & keep) ^ flip is ONE v_bitop3_b32
   }
 #pragma unroll
-  for (int i = 0; i < G::NTT; ++i) toff[i] = 16 * min(lane + 64 * i, G::KS - 1);
+  for (int i = 0; i < NTT; ++i) toff[i] = 16 * min(lane + 64 * i, NTG - 1);
   auto ld_grp = [&](int g) {
-    const int cw = SEP2_CH * g + 16 * wave;                  // (wave-uniform: the bases below are scalar)
+    const int cw = GCH * g + RCH * wave;                     // (wave-uniform: the bases below are scalar)
     const int8_t* const xg = p.x + ((size_t)b * CIN_PAD + cw) * eTp;
     const unsigned char* const tg = (const unsigned char*)p.wdw2 + (size_t)cw * G::KS;   // zero-margined tap rows [C][KS]
 #pragma unroll
-    for (int i = 0; i < G::NPT; ++i) pc[i] = *(const v4i*)(xg + woff[i]);
+    for (int i = 0; i < NPT; ++i) pc[i] = *(const v4i*)(xg + woff[i]);
 #pragma unroll
-    for (int i = 0; i < G::NTT; ++i) pt[i] = *(const v4i*)(tg + toff[i]);
+    for (int i = 0; i < NTT; ++i) pt[i] = *(const v4i*)(tg + toff[i]);
   };
   auto ld_res = [&](int i) {                                 // residual operand granule: channel gi / (TT/16), 16 frames
     if constexpr (RES) {
@@ -369,17 +382,26 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
   };
   auto commit = [&]() {                                      // registers -> this wave's LDS rows
 #pragma unroll
-    for (int i = 0; i < G::NPT; ++i) {
-      if (64 * i + 63 < 16 * G::NPG || lane + 64 * i < 16 * G::NPG) {
+    for (int i = 0; i < NPT; ++i) {
+      if (64 * i + 63 < RCH * NPGR || lane + 64 * i < RCH * NPGR) {
         v4i v = pc[i];
         v[0] = (v[0] & wkeep[i]) ^ flip; v[1] = (v[1] & wkeep[i]) ^ flip; v[2] = (v[2] & wkeep[i]) ^ flip; v[3] = (v[3] & wkeep[i]) ^ flip;
-        *(lds_v4i*)wlds[i] = v;
+        if constexpr (DIL == 1) {
+          *(lds_v4i*)wlds[i] = v;
+        } else {                                             // frames of one parity: bytes 0, 2, 4, 6 / 1, 3, 5, 7 of each dword pair
+          const v2i ev = {(int)__builtin_amdgcn_perm((unsigned)v[1], (unsigned)v[0], 0x06040200u),
+                          (int)__builtin_amdgcn_perm((unsigned)v[3], (unsigned)v[2], 0x06040200u)};
+          const v2i od = {(int)__builtin_amdgcn_perm((unsigned)v[1], (unsigned)v[0], 0x07050301u),
+                          (int)__builtin_amdgcn_perm((unsigned)v[3], (unsigned)v[2], 0x07050301u)};
+          *(lds_v2i*)wlds[i] = ev;
+          *(lds_v2i*)(wlds[i] + G::WP) = od;
+        }
       }
     }
 #pragma unroll
-    for (int i = 0; i < G::NTT; ++i) {
+    for (int i = 0; i < NTT; ++i) {
       const int gi = lane + 64 * i;
-      if (64 * i + 63 < G::KS || gi < G::KS) *(lds_v4i*)(Tlw + 16 * gi) = pt[i];
+      if (64 * i + 63 < NTG || gi < NTG) *(lds_v4i*)(Tlw + 16 * gi) = pt[i];
     }
   };
   // K == 0 (a bare 1x1 conv, e.g. block 17 of QuartzNet): no depthwise stage - the [channel][frame] tile of `x` IS the
@@ -408,7 +430,7 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
   if constexpr (K > 0) {
 #pragma unroll
     for (int gi = 0; gi < NCHUNK; ++gi) {
-      const int c = SEP2_CH * gi + 16 * wave + cb;           // a wave owns 16 channels of every chunk
+      const int c = GCH * gi + RCH * wave + cb / DIL;        // a wave owns 16 / DIL channels of every chunk
       dbias[gi] = p.bias_dw[c];
       dM[gi] = p.m_dw[c];
     }
@@ -456,7 +478,7 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
     unsigned xs[G::NRD * (G::RG / 4)];                       // the lane's window run: every dword feeds the NU chains
   };
   // the lane's two LDS streams, each behind a base register of its own: every read is base + immediate offset
-  const lds_u32* tr_lane = (const lds_u32*)(Tlw + cb * G::KS + 4 * tq);
+  const lds_u32* tr_lane = (const lds_u32*)(Tlw + (cb / DIL) * G::KS + 4 * tq);   // (DIL 2: both parities read their channel's taps)
   const lds_u8* wr_lane = Wsw + cb * G::WP + S * jl + (G::A0 & ~(G::RG - 1));
   asm volatile("" : "+v"(tr_lane), "+v"(wr_lane));
   auto dw_read = [&](DwIn& in) {                             // this wave's 16 channels: row = channel, lane (cb, jl)
@@ -485,6 +507,20 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
   };
   // masks, requantisation and the [channel][frame] image of one group
   auto dw_out = [&](v4i (&acc)[NU], int c0, double Mg) {
+    if constexpr (DIL == 2) {
+      // lane (cb, jl): channel cb >> 1, parity cb & 1, stream samples S jl + 4 u + v = frames 2 (..) + parity: one byte each
+      // (masked frames are zeroed in one pass over the finished image of the ONE tile that straddles the length)
+      const int c = c0 + RCH * wave + (cb >> 1), par = cb & 1;
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int f = 2 * (S * jl + 4 * u + v) + par;
+          if (DBG && p.dw_acc_dbg && t0 + f < eT) p.dw_acc_dbg[((size_t)b * CIN_PAD + c) * eTp + t0 + f] = acc[u][v];
+          *(lds_u8*)(Xd + (f >> 5) * (CIN_PAD * 32) + c * 32 + (f & 31)) = (unsigned char)rq_clamp(acc[u][v], Mg, dw_lo, dw_hi);
+        }
+      return;
+    }
     const int c = c0 + 16 * wave + cb;
     if (DBG && p.dw_acc_dbg) {
 #pragma unroll
@@ -583,22 +619,22 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
 #ifndef SEP2_ILV
 #define SEP2_ILV 1
 #endif
-  constexpr bool ILV = SEP2_ILV && (!RES || TT <= 64);       // (register budget of the block-end forms at 128 frames)
+  constexpr bool ILV = SEP2_ILV && (!RES || TT <= 64) && DIL == 1;   // (register budget of the block-end forms at 128 frames)
   v4i accs[ILV ? 2 : 1][NU];
   auto chunk = [&](auto chc) {
     constexpr int CH = decltype(chc)::value;
-    constexpr int c0 = SEP2_CH * CH;
+    constexpr int c0 = GCH * CH;
     constexpr int NPF = (CH + 1 == NCHUNK ? NRT : 0) + (CH < SLC ? 4 * NG * (CH + 1) / SLC - 4 * NG * CH / SLC : 0);
     constexpr int Q = (NPF + 2) / 3;                         // three issue points per group
     if constexpr (ILV) {
       if constexpr (CH == 0) dw_mfma(in, accs[0], dbias[0], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
       else {
         if (DBG && p.dw_acc_dbg) {                           // (debug builds: the plain order, accumulators dumped)
-          dw_out(accs[(CH - 1) & 1], c0 - SEP2_CH, dM[CH - 1]);
+          dw_out(accs[(CH - 1) & 1], c0 - GCH, dM[CH - 1]);
           dw_mfma(in, accs[CH & 1], dbias[CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); });
         } else {
           dw_mfma_ilv(in, accs[CH & 1], dbias[CH], [&](int k) { pf(chc, Q * k, Q * (k + 1)); }, accs[(CH - 1) & 1],
-                      c0 - SEP2_CH, dM[CH - 1]);
+                      c0 - GCH, dM[CH - 1]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -643,9 +679,22 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
       *(lds_v4i*)(Xd + (q >> 1) * (CIN_PAD * 32) + c * 32 + 16 * (q & 1)) = v;
     }
   }
-  static_assert(NCHUNK <= 4, "more than 512 input channels");
+  static_assert(NCHUNK <= 4 * DIL, "more than 512 input channels");
   if ((tune & 5) == 1) __builtin_amdgcn_s_setprio(0);        // (tune & 4: the priority stays through the GEMM passes)
   __syncthreads();                                           // Xd complete, windows dead
+  if constexpr (DIL == 2) {
+    if (t0 + TT > dlim) {                                    // (uniform) MaskedConv1d of the 1x1 conv: frames >= len are code 0
+      for (int r = tid; r < MT * CIN_PAD; r += SEP2_NT) {
+        const int mt = r / CIN_PAD, n = dlim - t0 - 32 * mt;  // valid frames of this 32-frame row
+        if (n < 32) {
+          lds_v4i* row = (lds_v4i*)(Xd + (size_t)r * 32);
+          row[0] = sep2_mask16(row[0], n);
+          row[1] = sep2_mask16(row[1], n - 16);
+        }
+      }
+      __syncthreads();
+    }
+  }
   if constexpr (RES) {                                       // residual A image [PCIN_PAD][32] per 32-frame tile
     const unsigned rflip = p.panes[0].x_unsigned ? 0x80808080u : 0u;
 #pragma unroll
@@ -864,15 +913,15 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
 #undef STAMP2
 }
 
-template <int K, int NG, int NGP, int NP, bool DBG, int TT>
+template <int K, int NG, int NGP, int NP, bool DBG, int TT, int DIL = 1>
 __global__ void __launch_bounds__(SEP2_NT, SEP2_WPE) k_sep2(SepP p) {
-  sep2_body<K, NG, NGP, NP, DBG, TT>(p, blockIdx.x, blockIdx.y * TT, blockIdx.x == 0 && blockIdx.y == 1,
-                                     blockIdx.y * gridDim.x + blockIdx.x);
+  sep2_body<K, NG, NGP, NP, DBG, TT, DIL>(p, blockIdx.x, blockIdx.y * TT, blockIdx.x == 0 && blockIdx.y == 1,
+                                          blockIdx.y * gridDim.x + blockIdx.x);
 }
 
-template <int K, int TT>
+template <int K, int TT, int DIL = 1>
 static inline size_t sep2_smem_bytes(const SepP& p) {
-  using G = Sep2Geo<K, TT>;
+  using G = Sep2Geo<K, TT / DIL>;
   const size_t xd = (size_t)TT * p.cin_pad;
   if (K == 0) return xd;
   size_t un = (size_t)(SEP2_NT / 64) * G::WREG;                                 // the waves' private window + tap rows
@@ -901,7 +950,7 @@ constexpr int sep2_shape_index(int K, int NG, int NGP, int NP) {
 // Shapes k_sep2 is built for; everything else stays on k_sep.
 static inline bool sep2_shape_ok(const SepP& p) {
   const EpiP& e = p.e;
-  if (p.K < 0 || p.dilation != 1 || p.dense_k > 1 || p.cin_pad & 127 || e.cout > 1024) return false;
+  if (p.K < 0 || (p.dilation != 1 && p.dilation != 2) || p.dense_k > 1 || p.cin_pad & 127 || e.cout > 1024) return false;
   if (e.flags & (QASR_F_LOGITS | QASR_F_WIDE_RQ)) return false;
   if (e.n_outs < 1) return false;
   int ngp = 0;
@@ -915,21 +964,22 @@ static inline bool sep2_shape_ok(const SepP& p) {
   }
   if (p.cin != p.cin_pad || (e.cout & 255) || (ngp && p.panes[0].cin != p.panes[0].cin_pad)) return false;   // exact shapes
   const int ng = p.cin_pad >> 7, np = (e.cout + 255) / 256;
+  if (p.K > 0 && p.dilation == 2) return p.K == 87 && ng == 4 && ngp == 0 && np == 2;   // QuartzNet's block 16 (64- / 128-frame tiles)
 #define SEP2_MATCH(K_, NG_, NGP_, NP_) if (p.K == K_ && ng == NG_ && ngp == NGP_ && np == NP_) return true;
   SEP2_INSTANCES(SEP2_MATCH)
 #undef SEP2_MATCH
   return false;
 }
 
-template <int K, int NG, int NGP, int NP, bool DBG, int TT>
+template <int K, int NG, int NGP, int NP, bool DBG, int TT, int DIL = 1>
 static int launch_sep2_v(hipStream_t s, const SepP& p) {
-  const size_t smem = sep2_smem_bytes<K, TT>(p);
+  const size_t smem = sep2_smem_bytes<K, TT, DIL>(p);
   if (smem > 160 * 1024 || p.e.B < 1 || p.e.Tp % TT || !p.x || !p.w || (K > 0 && !p.wdw2)) return QASR_ERR_ARG;
   static int attr_dev = -1;                                  // the attribute is per device
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (attr_dev != dev) {
-    (void)hipFuncSetAttribute((const void*)k_sep2<K, NG, NGP, NP, DBG, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_sep2<K, NG, NGP, NP, DBG, TT, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_dev = dev;
   }
   SepP q = p;
@@ -937,7 +987,7 @@ static int launch_sep2_v(hipStream_t s, const SepP& p) {
   static const int tune = getenv("QASR_SEP2_TUNE") ? atoi(getenv("QASR_SEP2_TUNE")) : 0;
   q.prof_mode = g_prof_mode | (tune << 8);
   q.prof_cap = g_prof_cap;
-  hipLaunchKernelGGL((k_sep2<K, NG, NGP, NP, DBG, TT>), dim3(p.e.B, p.e.Tp / TT, 1), dim3(SEP2_NT), smem, s, q);
+  hipLaunchKernelGGL((k_sep2<K, NG, NGP, NP, DBG, TT, DIL>), dim3(p.e.B, p.e.Tp / TT, 1), dim3(SEP2_NT), smem, s, q);
   return QASR_OK;
 }
 
@@ -945,6 +995,12 @@ static int launch_sep2_v(hipStream_t s, const SepP& p) {
 template <int TT, bool DBG>
 int launch_sep2_inst(hipStream_t s, const SepP& p) {
   const int ng = p.cin_pad >> 7, ngp = (p.e.flags & QASR_F_RESADD) ? (p.panes[0].cin_pad >> 7) : 0, np = (p.e.cout + 255) / 256;
+  if (p.K > 0 && p.dilation == 2) {                          // block 16: the dilation-2 form (64- / 128-frame tiles)
+    if constexpr (TT >= 64) {
+      if (p.K == 87 && ng == 4 && ngp == 0 && np == 2) return launch_sep2_v<87, 4, 0, 2, DBG, TT, 2>(s, p);
+    }
+    return QASR_ERR_UNSUPPORTED;
+  }
 #define SEP2_LAUNCH(K_, NG_, NGP_, NP_)                                                  \
   if constexpr (TT <= 64 || K_ > 0) {   /* the bare 1x1 form spills at 128 frames */       \
     if (p.K == K_ && ng == NG_ && ngp == NGP_ && np == NP_) return launch_sep2_v<K_, NG_, NGP_, NP_, DBG, TT>(s, p); \

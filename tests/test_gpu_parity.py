@@ -761,17 +761,35 @@ def test_sep_layer_production_kernels_against_oracle(eng, tile, K, cin, cout, rc
 
 
 def test_sep_layer_dilated_and_bare_1x1(eng):
-    """The shapes that stay on k_sep: the dilated depthwise layer of block 16 (K = 87, dilation 2) and a bare 1x1 conv."""
+    """The dilated depthwise layer of block 16 (K = 87, dilation 2) on round 1's k_sep AND on k_sep2's dilation-2 form (channels
+    staged as even / odd frame rows; debug and production instantiations, 64- and 128-frame tiles, lengths on the mask edges
+    incl. an odd one), and a bare 1x1 conv."""
     from qasr.pack import F_MASK_OUT, F_RELU
     rng = np.random.default_rng(87)
     c = _sep_case(rng, 2, 250, 512, 512, 87, True, None, 1)
     want = O.sep_layer_ref(c['x'], c['lens'], c['wdw'], c['m_dw'], (-128, 127), c['wpw'], c['bias'], c['outs'], dilation=2,
                            relu=True, mask_out=True)
-    for tile in (32, 64):
-        got = eng.sep_layer(torch.from_numpy(c['x'].astype(np.uint8)).cuda(), c['lens'], c['wpw'], c['bias'], c['outs'],
-                            wdw=c['wdw'], m_dw=c['m_dw'], x_unsigned=True, dilation=2, flags=F_RELU | F_MASK_OUT, tile=tile)
-        assert np.array_equal(got['dw_acc'].cpu().numpy(), want['dw_acc']) and np.array_equal(got['acc'].cpu().numpy(), want['acc'])
-        assert np.array_equal(got['outs'][0].cpu().numpy().view(np.uint8).astype(np.int64), want['outs'][0])
+    for gen, tiles in ((1, (32, 64)), (2, (32, 64, 128))):
+        for tile in tiles:
+            got = eng.sep_layer(torch.from_numpy(c['x'].astype(np.uint8)).cuda(), c['lens'], c['wpw'], c['bias'], c['outs'],
+                                wdw=c['wdw'], m_dw=c['m_dw'], x_unsigned=True, dilation=2, flags=F_RELU | F_MASK_OUT, tile=tile, gen=gen)
+            assert got['label'].startswith('k_sep2<87, 4, 0, 2, true') == (gen == 2), got['label']
+            assert np.array_equal(got['dw_acc'].cpu().numpy(), want['dw_acc']), (gen, tile)
+            assert np.array_equal(got['acc'].cpu().numpy(), want['acc']), (gen, tile)
+            assert np.array_equal(got['outs'][0].cpu().numpy().view(np.uint8).astype(np.int64), want['outs'][0]), (gen, tile)
+    c8 = _sep_case(rng, 8, 250, 512, 512, 87, True, None, 1)
+    lens = np.array([250, 249, 224, 209, 131, 100, 17, 1])
+    c8['lens'] = lens
+    c8['x'] = np.where(np.arange(250)[None, None, :] < lens[:, None, None], c8['x'], 0)
+    want8 = O.sep_layer_ref(c8['x'], lens, c8['wdw'], c8['m_dw'], (-128, 127), c8['wpw'], c8['bias'], c8['outs'], dilation=2,
+                            relu=True, mask_out=True)
+    for tile in (64, 128):
+        got = eng.sep_layer(torch.from_numpy(c8['x'].astype(np.uint8)).cuda(), lens, c8['wpw'], c8['bias'], c8['outs'],
+                            wdw=c8['wdw'], m_dw=c8['m_dw'], x_unsigned=True, dilation=2, flags=F_RELU | F_MASK_OUT, tile=tile, gen=2,
+                            hooks=False)
+        assert got['label'] == f'k_sep2<87, 4, 0, 2, false, {tile}, 2>', got['label']
+        g = got['outs'][0].cpu().numpy().view(np.uint8).astype(np.int64)
+        assert np.array_equal(g, want8['outs'][0]), (tile, int((g != want8['outs'][0]).sum()))
     want = O.sep_layer_ref(c['x'], c['lens'], None, None, None, c['wpw'], c['bias'], c['outs'], relu=True, mask_out=True)
     got = eng.sep_layer(torch.from_numpy(c['x'].astype(np.uint8)).cuda(), c['lens'], c['wpw'], c['bias'], c['outs'],
                         x_unsigned=True, flags=F_RELU | F_MASK_OUT)
