@@ -286,12 +286,26 @@ typedef struct qasr_dyn_view {
   const void* data;            /* int32 [B][C][Tp] accumulators, or int8 [B][C][Tp] codes (is_int8) */
   const float* scale;          /* f32 [C] (per_channel) or [1] */
   int32_t is_int8, per_channel;
+  /* Optional (both or neither; accumulators only): the reference's conv_int is F.conv1d in double over
+   * x_int = fl32(x / pre_sf) (quant_modules.py:301-305), and that float32 quotient is the integer or a float32 neighbour
+   * of it - conv_int = integers + sum(w residue), rounded once by .type(torch.float).  residue_lo + 128 residue_hi is that
+   * sum in units of 2^-24 (the int_conv accumulators of the two tensors qasr_dyn_residue_codes writes, no bias).  It never
+   * changes a code, but it is in the float tensor a dynamic QuantAct ranges over. */
+  const int32_t* residue_lo;
+  const int32_t* residue_hi;
 } qasr_dyn_view;
 /* x_act.min() / .max() (quant_modules.py:152-153): x_act = relu?(a) (+ b as the identity), zero where t >= lens[b]
  * (MaskedConv1d's mask, jasper.py:177-181; lens NULL: no mask), over t < T.  xf != NULL: the tensor is the float input
  * itself, [B][C][Tx] (first layer).  minmax: two order-preserving encodings of the float32 min / max. */
 int qasr_dyn_range(void* stream, const qasr_dyn_view* a, const qasr_dyn_view* b, const float* xf, int Tx,
                    const int32_t* lens, int relu, int B, int C, int T, int Tp, uint32_t* minmax);
+/* The percentile form of the same range (qm.set_percentile in force, quant_modules.py:158-167): minmax =
+ * (torch.quantile(x_act, q_lo), torch.quantile(x_act, q_hi)) over ALL B C T elements, masked zeros included, in the
+ * encoding of qasr_dyn_range.  x_act: device scratch of B C T floats (the tensor is written out once, then
+ * qasr_quantile2 selects on it); workspace as for qasr_quantile2. */
+int qasr_dyn_range_percentile(void* stream, const qasr_dyn_view* a, const qasr_dyn_view* b, const float* xf, int Tx,
+                              const int32_t* lens, int relu, int B, int C, int T, int Tp, float q_lo, float q_hi,
+                              float* x_act, void* workspace, size_t workspace_bytes, uint32_t* minmax);
 /* act_scaling_factor = max(|min|, |max|, 1e-8) / (2^(bits-1) - 1) (quant_utils.py:44-54) -> s_out[0]; per channel the
  * fixedpoint_mul multiplier m 2^-e of f64(pre_sf[c]) / f64(act_sf) with (m, e) = batch_frexp (quant_utils.py:121-147,
  * 190-196) as float64 -> Ma[c] (operand a, scales sa) and Mb[c] (operand b, scales sb; NULL: none). */
@@ -304,6 +318,10 @@ int qasr_dyn_requant(void* stream, const qasr_dyn_view* a, const double* Ma, con
 /* first layer (quant_modules.py:180-184): s_out[0] = act_scaling_factor, out = clamp(round(fl32(1/s) x), -n, n-1) */
 int qasr_dyn_quant_in(void* stream, const float* x, int Tx, const uint32_t* minmax, const int32_t* lens, int bits, int B,
                       int C, int T, int Tp, float* s_out, int8_t* out);
+/* residue(q) = fl32(fl32(q s_x[0]) / s_x[0]) - q of every code byte (see qasr_dyn_view), in units of 2^-24, as
+ * lo + 128 hi with |lo| <= 64, |hi| <= 2: two s8 tensors of n bytes (n a multiple of 16, 16-byte aligned pointers). */
+int qasr_dyn_residue_codes(void* stream, const int8_t* codes, int x_unsigned, const float* s_x, size_t n, int8_t* lo,
+                           int8_t* hi);
 /* the conv that consumes those codes (quant_modules.py:293-299,307): sf_out[c] = s_w[c] s_x, bias[c] =
  * clamp(round(fl32(1/sf_out[c]) bprime[c])) evaluated in float32 (+ wsum128[c] = 128 sum(W[c]) when the codes are
  * stored as u8); rows C..C_pad-1: scale 1, bias 0. */

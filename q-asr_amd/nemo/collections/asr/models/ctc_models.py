@@ -163,10 +163,14 @@ class EncDecCTCModel(nn.Module):
         return all(mc.conv.fix_bn and mc.conv.quant_mode == 'symmetric' for mc in self._masked_convs())
 
     def dynamic_ready(self):
-        """True when every QuantAct is in dynamic mode (qm.set_dynamic, quant_modules.py:149-167) on min / max ranges and
-        the convs are folded and fixed: the configuration qasr.dynamic.DynamicRunner executes on the HIP kernels."""
+        """True when every QuantAct is in dynamic mode (qm.set_dynamic, quant_modules.py:149-167) on min / max or - all of
+        them alike - percentile ranges (qm.set_percentile, :158-167) and the convs are folded and fixed: the configuration
+        qasr.dynamic.DynamicRunner executes on the HIP kernels.  (Per-channel activation ranges are not a configuration the
+        reference's QuantConv1d can run: int_conv multiplies [Cout,1,1] weight scales with [1,Cin,1] activation scales.)"""
         acts = [m for m in self.modules() if isinstance(m, QuantAct)]
-        if not acts or any(a.quant_mode != 'symmetric' or not a.dynamic or a.percentile or a.per_channel for a in acts):
+        if not acts or any(a.quant_mode != 'symmetric' or not a.dynamic or a.per_channel for a in acts):
+            return False
+        if len({a.percentile or None for a in acts}) != 1:
             return False
         for blk in self.encoder.encoder_layers:
             if any(isinstance(l, nn.BatchNorm1d) for l in blk.mconv):
@@ -176,13 +180,14 @@ class EncDecCTCModel(nn.Module):
     def _get_dynamic_runner(self, device):
         """DynamicRunner for the live weights (both model families), or None if it declines the topology: such a model
         keeps the host modules in dynamic mode."""
-        key = ('dyn', self._quant_version, device.index or 0)
+        percentile = next(m for m in self.modules() if isinstance(m, QuantAct)).percentile or None
+        key = ('dyn', self._quant_version, device.index or 0, percentile)
         if self._engine_key != key:
             from qasr import dynamic, engine as qengine
             qengine.load_library()
             cfg, sd, _, _, wbit, abit = self.export_pack_inputs()
             try:
-                self._engine = dynamic.DynamicRunner(cfg, sd, wbit, abit, device)
+                self._engine = dynamic.DynamicRunner(cfg, sd, wbit, abit, device, percentile=percentile)
             except NotImplementedError:
                 self._engine = None
             self._engine_key = key

@@ -6,7 +6,8 @@ scales, fixedpoint_mul multipliers (batch_frexp, quant_utils.py:121-147) and the
 (quant_modules.py:293-299) are recomputed per batch.  The reference does that through host numpy and fp64 tensor
 arithmetic with a device->host->device round trip per QuantAct; `DynamicRunner` keeps the derivation on the GPU:
 
-    QuantAct   qasr_dyn_range (min / max of the float32 view) -> qasr_dyn_act_params (scale, m 2^-e per channel)
+    QuantAct   qasr_dyn_range (min / max of the float32 view; with qm.set_percentile in force qasr_dyn_range_percentile:
+               the two torch.quantile values, quant_modules.py:158-167) -> qasr_dyn_act_params (scale, m 2^-e per channel)
                -> qasr_dyn_requant (int8 / uint8 codes, MaskedConv1d's mask applied)
     QuantConv  qasr_dyn_conv_params (output scales, bias integers) -> qasr_dw_conv_acc / qasr_pw_conv_acc (int32)
 
@@ -33,19 +34,23 @@ def _rup(x, m):
 
 
 class DynView(C.Structure):
-    _fields_ = [('data', C.c_void_p), ('scale', C.c_void_p), ('is_int8', C.c_int32), ('per_channel', C.c_int32)]
+    _fields_ = [('data', C.c_void_p), ('scale', C.c_void_p), ('is_int8', C.c_int32), ('per_channel', C.c_int32),
+                ('residue_lo', C.c_void_p), ('residue_hi', C.c_void_p)]
 
 
 class _Value:
     """A float32 tensor as integers x scales: `data` int32 / int8 [B, C, Tp], `scale` f32 [C] or [1]."""
 
-    def __init__(self, data, scale, C_, T, per_channel, relu=False, feats=None):
+    def __init__(self, data, scale, C_, T, per_channel, relu=False, feats=None, residue=None):
         self.data, self.scale, self.C, self.T, self.per_channel, self.relu, self.feats = data, scale, C_, T, per_channel, relu, feats
+        self.residue = residue                                # (lo, hi) int32 accumulators: sum(w residue) in units of 2^-24
 
     def view(self):
         v = DynView()
         v.data, v.scale = self.data.data_ptr(), self.scale.data_ptr()
         v.is_int8, v.per_channel = int(self.data.dtype == torch.int8), int(self.per_channel)
+        if self.residue is not None:
+            v.residue_lo, v.residue_hi = self.residue[0].data_ptr(), self.residue[1].data_ptr()
         return v
 
 
@@ -85,10 +90,17 @@ class _Conv:
 class DynamicRunner:
     """ConvASREncoder.forward + ConvASRDecoder.forward (conv_asr.py:194-206,270-275) in dynamic mode on the HIP kernels."""
 
-    def __init__(self, cfg, state_dict, wbit=8, abit=8, device='cuda:0'):
+    def __init__(self, cfg, state_dict, wbit=8, abit=8, device='cuda:0', percentile=None, division_residue=True):
         self.cfg, self.wbit, self.abit = cfg, wbit, abit
+        # the reference's conv_int is a double conv over fl32(x / pre_sf), not over the integers (quant_modules.py:301-305):
+        # carry the difference (two extra integer convs per layer) so that every range is taken over the float tensor the
+        # reference's QuantAct sees, bit for bit.  False: float view = integer x scale (a range may differ in its last bit)
+        self.division_residue = division_residue
+        self.percentile = percentile or None                  # `if not self.percentile` (quant_modules.py:150): 0 = min / max
         self.dev = torch.device(device)
         self.lib = load_library()
+        self._qws = torch.empty(self.lib.qasr_quantile_workspace_bytes(), dtype=torch.uint8, device=self.dev)
+        self._xact = None                                     # scratch: x_act as float32 for the radix select
         self.plan = conv_plan(cfg)
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if torch.is_tensor(v)}
         self.convs = {}
@@ -102,17 +114,28 @@ class DynamicRunner:
         self.dec = _Conv(None, sd['decoder.decoder_layers.0.weight'], sd['decoder.decoder_layers.0.bias'], wbit, self.dev)
         self.trace = None                                     # tests: list of dicts per conv (acc, codes, scales)
 
+    def close(self):
+        """Drop the device tensors (the model facade calls this when its quantisation state changes, like Engine.close)."""
+        self.convs, self.dec, self._xact = {}, None, None
+
     # ------------------------------------------------------------------ kernels
     def _range(self, a, b, lens, relu, B, T, Tp):
         mm = torch.empty(2, dtype=torch.int32, device=self.dev)
         if a.feats is not None:
-            x = a.feats
-            _check(self.lib.qasr_dyn_range(_stream_ptr(), None, None, _ptr(x), x.shape[2], _ptr(lens), 0, B, a.C, T, Tp,
-                                           _ptr(mm)), 'qasr_dyn_range')
+            args = (None, None, _ptr(a.feats), a.feats.shape[2], _ptr(lens), 0, B, a.C, T, Tp)
         else:
             va, vb = a.view(), (b.view() if b is not None else None)
-            _check(self.lib.qasr_dyn_range(_stream_ptr(), C.byref(va), C.byref(vb) if vb is not None else None, None, 0,
-                                           _ptr(lens), int(relu), B, a.C, T, Tp, _ptr(mm)), 'qasr_dyn_range')
+            args = (C.byref(va), C.byref(vb) if vb is not None else None, None, 0, _ptr(lens), int(relu), B, a.C, T, Tp)
+        if self.percentile is None:
+            _check(self.lib.qasr_dyn_range(_stream_ptr(), *args, _ptr(mm)), 'qasr_dyn_range')
+            return mm
+        n = B * a.C * T
+        if self._xact is None or self._xact.numel() < n:
+            self._xact = torch.empty(n, dtype=torch.float32, device=self.dev)
+        # torch.tensor(1 - p / 100) / torch.tensor(p / 100) (quant_modules.py:161,165): float32 roundings of the doubles
+        _check(self.lib.qasr_dyn_range_percentile(_stream_ptr(), *args, C.c_float(1 - self.percentile / 100),
+                                                  C.c_float(self.percentile / 100), _ptr(self._xact), _ptr(self._qws),
+                                                  self._qws.numel(), _ptr(mm)), 'qasr_dyn_range_percentile')
         return mm
 
     def _quant_act(self, v, bits, unsigned, lens, B, ident=None, mask=True):
@@ -153,22 +176,33 @@ class DynamicRunner:
         Tp = codes.shape[2]
         T_out = (T + 2 * padding - dilation * (kernel - 1) - 1) // stride + 1
         Tpo = _rup(T_out, 64)
-        acc = torch.zeros(B, cv.cout, Tpo, dtype=torch.int32, device=self.dev)
-        if cv.dense:
-            _check(self.lib.qasr_dense_conv_acc(_stream_ptr(), _ptr(codes), int(unsigned), _ptr(cv.w), _ptr(bias), B, codes.shape[1],
-                                                cv.cin_pad, cv.cout, kernel, stride, dilation, padding, T, Tp, T_out, Tpo,
-                                                _ptr(acc)), 'qasr_dense_conv_acc')
-        elif cv.site is not None and cv.site.role == 'dw':
-            _check(self.lib.qasr_dw_conv_acc(_stream_ptr(), _ptr(codes), int(unsigned), _ptr(cv.w), _ptr(bias), B, cv.cout,
-                                             kernel, cv.kpad, stride, dilation, padding, T, Tp, T_out, Tpo, _ptr(acc)),
-                   'qasr_dw_conv_acc')
-        else:
-            _check(self.lib.qasr_pw_conv_acc(_stream_ptr(), _ptr(codes), int(unsigned), _ptr(cv.w), _ptr(bias), B,
-                                             codes.shape[1], cv.cin_pad, cv.cout, T, Tp, _ptr(acc)), 'qasr_pw_conv_acc')
+
+        def int_conv(x, x_unsigned, b):
+            acc = torch.zeros(B, cv.cout, Tpo, dtype=torch.int32, device=self.dev)
+            if cv.dense:
+                _check(self.lib.qasr_dense_conv_acc(_stream_ptr(), _ptr(x), int(x_unsigned), _ptr(cv.w), _ptr(b), B, x.shape[1],
+                                                    cv.cin_pad, cv.cout, kernel, stride, dilation, padding, T, Tp, T_out, Tpo,
+                                                    _ptr(acc)), 'qasr_dense_conv_acc')
+            elif cv.site is not None and cv.site.role == 'dw':
+                _check(self.lib.qasr_dw_conv_acc(_stream_ptr(), _ptr(x), int(x_unsigned), _ptr(cv.w), _ptr(b), B, cv.cout,
+                                                 kernel, cv.kpad, stride, dilation, padding, T, Tp, T_out, Tpo, _ptr(acc)),
+                       'qasr_dw_conv_acc')
+            else:
+                _check(self.lib.qasr_pw_conv_acc(_stream_ptr(), _ptr(x), int(x_unsigned), _ptr(cv.w), _ptr(b), B,
+                                                 x.shape[1], cv.cin_pad, cv.cout, T, Tp, _ptr(acc)), 'qasr_pw_conv_acc')
+            return acc
+
+        acc = int_conv(codes, unsigned, bias)
+        residue = None
+        if self.division_residue:
+            lo, hi = torch.empty_like(codes), torch.empty_like(codes)
+            _check(self.lib.qasr_dyn_residue_codes(_stream_ptr(), _ptr(codes), int(unsigned), _ptr(s_x), codes.numel(), _ptr(lo),
+                                                   _ptr(hi)), 'qasr_dyn_residue_codes')
+            residue = (int_conv(lo, False, None), int_conv(hi, False, None))
         if self.trace is not None:
             self.trace.append(dict(key=cv.site.key if cv.site is not None else 'decoder', acc=acc[:, :, :T_out], codes=codes[:, :, :T],
                                    unsigned=unsigned, s_x=s_x, s_b=sf[:cv.cout]))
-        return _Value(acc, sf, cv.cout, T_out, True)
+        return _Value(acc, sf, cv.cout, T_out, True, residue=residue)
 
     def _masked_conv(self, s, v, lens, B):
         """MaskedConv1d.forward (jasper.py:175-194): mask -> QuantAct -> QuantConv1d; lens -> get_seq_len."""
@@ -206,6 +240,10 @@ class DynamicRunner:
         # decoder (conv_asr.py:270-275): QuantAct (signed) -> 1x1 conv with bias -> log_softmax
         codes, S = self._quant_act(cur, self.abit, False, lens, B, mask=False)
         out = self._conv(self.dec, codes, S, False, B, cur.T)
-        logits = (out.data[:, :, :out.T].float() * out.scale[:out.C].view(1, -1, 1))
+        z = out.data[:, :, :out.T]
+        if out.residue is not None:                           # conv_int.type(torch.float): integers + residue, rounded once
+            r = out.residue[0][:, :, :out.T].double() + 128.0 * out.residue[1][:, :, :out.T].double()
+            z = z.double() + r * 2.0 ** -24
+        logits = z.float() * out.scale[:out.C].view(1, -1, 1)
         logp = torch.log_softmax(logits.transpose(1, 2), dim=-1)
         return dict(log_probs=logp, tokens=logp.argmax(-1), enc_len=lens, logits=logits)

@@ -14,7 +14,7 @@ SYMBOLS = ['qasr_engine_create', 'qasr_engine_create_ex', 'qasr_engine_default_o
            'qasr_engine_time_ops', 'qasr_engine_run_op', 'qasr_engine_op_label',
            'qasr_frontend_mel', 'qasr_frontend_plan', 'qasr_frontend_mel_planned', 'qasr_frontend_frames',
            'qasr_frontend_workspace_bytes', 'qasr_pw_conv_acc',
-           'qasr_dw_conv_acc', 'qasr_dense_conv_acc', 'qasr_requant', 'qasr_dyn_range', 'qasr_dyn_act_params', 'qasr_dyn_requant',
+           'qasr_dw_conv_acc', 'qasr_dense_conv_acc', 'qasr_requant', 'qasr_dyn_range', 'qasr_dyn_range_percentile', 'qasr_dyn_residue_codes', 'qasr_dyn_act_params', 'qasr_dyn_requant',
            'qasr_dyn_quant_in', 'qasr_dyn_conv_params', 'qasr_sep_layer', 'qasr_quantile2', 'qasr_quantile_workspace_bytes', 'qasr_debug_prof',
            'qasr_debug_timeline',
            'qasr_last_error', 'qasr_version']
@@ -88,6 +88,8 @@ def load_library():
     lib.qasr_dense_conv_acc.argtypes = [vp, vp, i32, vp, vp] + [i32] * 12 + [vp]
     lib.qasr_requant.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.qasr_dyn_range.argtypes = [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]
+    lib.qasr_dyn_residue_codes.argtypes = [vp, vp, i32, vp, sz, vp, vp]
+    lib.qasr_dyn_range_percentile.argtypes = [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, C.c_float, C.c_float, vp, vp, sz, vp]
     lib.qasr_dyn_act_params.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, vp]
     lib.qasr_dyn_requant.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.qasr_dyn_quant_in.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp]

@@ -498,6 +498,10 @@ if __name__ == '__main__':
         run_net('net_miniq_dyn_w8a8', M['MiniQuartzNet'](), 7, 8, 8, None, 3, 96, (96, 71, 40), 0, 0, True, dynamic=True)
         run_net('net_miniq_dyn_w6a6', M['MiniQuartzNet'](), 8, 6, 6, None, 2, 80, (80, 33), 0, 0, True, dynamic=True)
         run_net('net_quartznet_dyn_w8a8', M['QuartzNet15x5Base-En'](), 9, 8, 8, None, 2, 64, (64, 41), 0, 0, False, dynamic=True)
+    if not which or 'dynamic_pct' in which:               # --dynamic --percentile: torch.quantile ranges per batch
+        run_net('net_miniq_dynp_w8a8', M['MiniQuartzNet'](), 12, 8, 8, 99.0, 3, 96, (96, 71, 40), 0, 0, True, dynamic=True)
+        run_net('net_minij_dynp_w6a6', M['MiniJasper'](), 13, 6, 6, 99.9, 2, 80, (80, 37), 0, 0, True, dynamic=True)
+        run_net('net_quartznet_dynp_w8a8', M['QuartzNet15x5Base-En'](), 14, 8, 8, 99.9, 2, 64, (64, 41), 0, 0, False, dynamic=True)
     if not which or 'dynamic_jasper' in which:
         run_net('net_minij_dyn_w8a8', M['MiniJasper'](), 10, 8, 8, None, 3, 96, (96, 80, 37), 0, 0, True, dynamic=True)
         run_net('net_jasper_dyn_w8a8', M['Jasper10x5Dr-En'](), 11, 8, 8, None, 2, 64, (64, 41), 0, 0, False, dynamic=True)

@@ -33,11 +33,12 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_packer(tmp_path):
     probe = tmp_path / 'probe.c'
-    probe.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "qasr.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    probe.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "qasr.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                      'sizeof(qasr_blob_header),sizeof(qasr_tensor_desc),sizeof(qasr_op_desc),sizeof(qasr_out),'
                      'sizeof(qasr_pane),sizeof(qasr_domain_desc),sizeof(qasr_sep_layer_args),'
                      'offsetof(qasr_sep_layer_args, outs),offsetof(qasr_sep_layer_args, racc),'
-                     'sizeof(qasr_engine_opts),offsetof(qasr_engine_opts, tile_frames),offsetof(qasr_engine_opts, persistent));return 0;}\n')
+                     'sizeof(qasr_engine_opts),offsetof(qasr_engine_opts, tile_frames),offsetof(qasr_engine_opts, persistent),'
+                     'sizeof(qasr_dyn_view),offsetof(qasr_dyn_view, residue_hi));return 0;}\n')
     exe = tmp_path / 'probe'
     subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(probe), '-o', str(exe)], check=True)
     sizes = list(map(int, subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()))
@@ -51,6 +52,8 @@ def test_struct_sizes_match_packer(tmp_path):
     assert sizes[7] == engine.SepLayerArgs.outs.offset and sizes[8] == engine.SepLayerArgs.racc.offset
     assert sizes[9] == ctypes.sizeof(engine.EngineOpts) == 64      # the engine's launch-plan options (qasr_engine_create_ex)
     assert sizes[10] == engine.EngineOpts.tile_frames.offset and sizes[11] == engine.EngineOpts.persistent.offset
+    from qasr import dynamic                                  # a float tensor as integers x scales (+ division residue)
+    assert sizes[12] == ctypes.sizeof(dynamic.DynView) and sizes[13] == dynamic.DynView.residue_hi.offset
 
 
 def test_engine_opts_defaults_and_validation():

@@ -40,7 +40,7 @@ def _run(golden_dir, name):
     d, meta = _load(golden_dir, name)
     cfg = _cfg(name)
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, meta['seed']).items()}
-    r = dynamic.DynamicRunner(cfg, sd, meta['wbit'], meta['abit'], 'cuda:0')
+    r = dynamic.DynamicRunner(cfg, sd, meta['wbit'], meta['abit'], 'cuda:0', percentile=meta.get('percentile'))
     r.trace = []
     x = synth.make_features(meta['batch'], cfg.feat_in, meta['frames'], meta['seed'])
     out = r.forward(torch.from_numpy(x).cuda(), torch.tensor(meta['lengths']))
@@ -52,10 +52,12 @@ def _codes(t):
     return (c.view(torch.uint8) if t['unsigned'] else c).cpu().numpy().astype(np.int64)
 
 
-@pytest.mark.parametrize('name', ['net_miniq_dyn_w8a8', 'net_miniq_dyn_w6a6', 'net_minij_dyn_w8a8'])
+@pytest.mark.parametrize('name', ['net_miniq_dyn_w8a8', 'net_miniq_dyn_w6a6', 'net_minij_dyn_w8a8', 'net_miniq_dynp_w8a8',
+                                  'net_minij_dynp_w6a6'])
 def test_dynamic_mini_net_every_accumulator(golden_dir, name):
     """Every conv's input codes and int32 accumulator equal the reference's rint(x_int) / rint(conv_int) in dynamic
-    mode (ragged lengths: the mask is part of what each QuantAct ranges over), then lengths, tokens and logits."""
+    mode (ragged lengths: the mask is part of what each QuantAct ranges over), then lengths, tokens and logits.  `dynp`:
+    --dynamic with --percentile (every range = two torch.quantile values of the batch, quant_modules.py:158-167)."""
     d, meta, r, out = _run(golden_dir, name)
     assert len(r.trace) == meta['nconv']
     for i, t in enumerate(r.trace):
@@ -67,7 +69,7 @@ def test_dynamic_mini_net_every_accumulator(golden_dir, name):
     np.testing.assert_allclose(out['log_probs'].cpu().numpy(), d['log_probs'], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize('name', ['net_quartznet_dyn_w8a8', 'net_jasper_dyn_w8a8'])
+@pytest.mark.parametrize('name', ['net_quartznet_dyn_w8a8', 'net_jasper_dyn_w8a8', 'net_quartznet_dynp_w8a8'])
 def test_dynamic_full_net_checksums(golden_dir, name):
     """All 171 convs of QuartzNet15x5 / all 109 of Jasper10x5dr (dense k>1 and strided convs, up to ten sequentially
     re-ranged residual panes per block) in dynamic mode: checksums of accumulators and input codes, tokens."""
@@ -80,20 +82,53 @@ def test_dynamic_full_net_checksums(golden_dir, name):
     np.testing.assert_allclose(out['logits'].cpu().numpy(), d['logits'], rtol=1e-5, atol=1e-5)
 
 
-def test_dynamic_batch1_against_oracle():
-    """BASELINE.json config 1 shape (B = 1, --dynamic) on inputs the fixtures do not hold: the oracle's dynamic mode
-    (pinned by the fixtures above on CPU) is the checker."""
+@pytest.mark.parametrize('percentile', [None, 99.5])
+@pytest.mark.parametrize('residue', [True, False])
+def test_dynamic_batch1_against_oracle(percentile, residue):
+    """BASELINE.json config 1 shape (B = 1, --dynamic, with and without --percentile) on inputs the fixtures do not hold:
+    the oracle's dynamic mode (pinned by the fixtures above on CPU) is the checker.  residue: with the reference's float32
+    quotient residue in every float view (what the reference computes, the runner's default) and without it (float view =
+    integer x scale) - the two arithmetics the oracle and the runner both implement."""
     cfg = topology.mini_quartznet()
     sdn = synth.make_state_dict(cfg, 21)
     x = synth.make_features(1, cfg.feat_in, 200, 5)
-    net = O.OracleNet(topology.conv_plan(cfg), cfg, sdn, None, None, 8, 8, dynamic=True)
+    net = O.OracleNet(topology.conv_plan(cfg), cfg, sdn, None, None, 8, 8, dynamic=True, percentile=percentile,
+                      division_residue=residue)
     want = net.forward(x, [200])
-    r = dynamic.DynamicRunner(cfg, {k: torch.from_numpy(v) for k, v in sdn.items()}, 8, 8, 'cuda:0')
+    r = dynamic.DynamicRunner(cfg, {k: torch.from_numpy(v) for k, v in sdn.items()}, 8, 8, 'cuda:0', percentile=percentile,
+                              division_residue=residue)
     r.trace = []
     out = r.forward(torch.from_numpy(x).cuda(), torch.tensor([200]))
     for i, (t, w) in enumerate(zip(r.trace, net.trace)):
+        assert float(t['s_x'][0]) == float(w['s_x']), (i, t['key'])
         assert np.array_equal(t['acc'].cpu().numpy(), w['acc']), (i, t['key'])
     assert np.array_equal(out['tokens'].cpu().numpy(), want['tokens'])
+    np.testing.assert_array_equal(out['logits'].cpu().numpy(), want['logits'])
+
+
+def test_dynamic_residue_codes():
+    """qasr_dyn_residue_codes: fl32(fl32(q s) / s) - q for every code value (signed and u8) and a spread of scales against
+    the oracle's division_residue, reassembled from the (lo, hi) bytes."""
+    from qasr import engine
+    lib = engine.load_library()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(3)
+    scales = np.concatenate([np.exp(rng.uniform(-20, 2, 60)), [1e-8 / 127, 1.0, 3.0, 1 / 3]]).astype(np.float32)
+    nonzero = 0
+    for unsigned in (0, 1):
+        q = np.arange(256, dtype=np.uint8) if unsigned else np.arange(-128, 128).astype(np.int8)
+        codes = torch.from_numpy(q.view(np.int8).copy()).to(dev)
+        for s in scales:
+            lo, hi = torch.empty_like(codes), torch.empty_like(codes)
+            sx = torch.tensor([s], dtype=torch.float32, device=dev)
+            engine._check(lib.qasr_dyn_residue_codes(engine._stream_ptr(), engine._ptr(codes), unsigned, engine._ptr(sx), 256,
+                                                     engine._ptr(lo), engine._ptr(hi)), 'residue_codes')
+            lo, hi = lo.cpu().numpy().astype(np.int64), hi.cpu().numpy().astype(np.int64)
+            assert np.abs(lo).max() <= 64 and np.abs(hi).max() <= 2
+            want = O.division_residue(q.astype(np.int64), s)
+            assert np.array_equal((lo + 128 * hi).astype(np.float64) * 2.0 ** -24, want), (unsigned, s)
+            nonzero += int((want != 0).sum())
+    assert nonzero > 1000                                     # the residue is common, not a corner case
 
 
 def test_dynamic_kernels_edge_cases():
@@ -160,5 +195,14 @@ def test_model_dynamic_mode_runs_on_device():
     enc, enc_len, sf = m.encoder(audio_signal=x, length=L)              # host modules, dynamic
     ref = m.decoder(encoder_output=enc, encoder_output_scaling_factor=sf)
     assert torch.equal(el.cpu(), enc_len.cpu().long())
+    agree = (ref.argmax(-1) == tok).float().mean().item()
+    assert agree >= 0.99, agree
+    # --dynamic --percentile (inference.py:101,110-112): same route, ranges from the radix select
+    qm.set_percentile(m, 99.9)
+    assert m.dynamic_ready()
+    lp, el, tok = m(processed_signal=x, processed_signal_length=L)
+    assert isinstance(m._engine, dynamic.DynamicRunner) and m._engine.percentile == 99.9
+    enc, enc_len, sf = m.encoder(audio_signal=x, length=L)
+    ref = m.decoder(encoder_output=enc, encoder_output_scaling_factor=sf)
     agree = (ref.argmax(-1) == tok).float().mean().item()
     assert agree >= 0.99, agree

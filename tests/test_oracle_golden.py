@@ -9,8 +9,9 @@ import pytest
 from oracle import int_oracle as O
 from qasr import synth, topology
 
-NETS = ['net_miniq_w8a8', 'net_miniq_w8a8_pct', 'net_miniq_w6a6', 'net_minij_w8a8', 'net_miniq_dyn_w8a8', 'net_miniq_dyn_w6a6', 'net_minij_dyn_w8a8']
-FULL = ['net_quartznet_w8a8', 'net_quartznet_w6a6', 'net_jasper_w8a8', 'net_quartznet_dyn_w8a8', 'net_jasper_dyn_w8a8']
+NETS = ['net_miniq_w8a8', 'net_miniq_w8a8_pct', 'net_miniq_w6a6', 'net_minij_w8a8', 'net_miniq_dyn_w8a8', 'net_miniq_dyn_w6a6', 'net_minij_dyn_w8a8', 'net_miniq_dynp_w8a8',
+        'net_minij_dynp_w6a6']
+FULL = ['net_quartznet_w8a8', 'net_quartznet_w6a6', 'net_jasper_w8a8', 'net_quartznet_dyn_w8a8', 'net_jasper_dyn_w8a8', 'net_quartznet_dynp_w8a8']
 
 
 def load(golden_dir, name):
@@ -39,7 +40,8 @@ def _forward(golden_dir, name):
     cfg = _model_cfg(name)
     sd = synth.make_state_dict(cfg, meta['seed'])
     net = O.OracleNet(topology.conv_plan(cfg), cfg, sd, d['act_min'], d['act_max'], meta['wbit'], meta['abit'],
-                      dynamic=meta.get('dynamic', False))
+                      dynamic=meta.get('dynamic', False), percentile=meta.get('percentile'),
+                      division_residue=meta.get('dynamic', False))
     x = synth.make_features(meta['batch'], cfg.feat_in, meta['frames'], meta['seed'])
     out = net.forward(x, meta['lengths'])
     return d, meta, net, out
@@ -154,7 +156,7 @@ def test_ctc_greedy_decode():
     assert O.ctc_greedy_decode(toks, vocab) == ['ccat', '']
 
 
-@pytest.mark.parametrize('name', [n for n in NETS if '_dyn_' not in n] + ['net_quartznet_w8a8'])
+@pytest.mark.parametrize('name', [n for n in NETS if '_dyn' not in n] + ['net_quartznet_w8a8'])
 def test_cpu_baseline_port_matches_reference(golden_dir, name):
     """oracle/fakequant_torch.py (the op sequence bench.py times as cpu_baseline) against the fixtures."""
     from oracle.fakequant_torch import FakeQuantNet
