@@ -180,7 +180,9 @@ class QuantConv1d(Module):
         bint, s_b = Q.bias_integers(bias, s_w, pre_act_scaling_factor, self.bias_bit or 32)
         if bint is not None:
             self.bias_integer = bint
-        x_int = torch.round(x / pre_act_scaling_factor).double()
+        # no rounding here, as in the reference (quant_modules.py:301): the float32 quotient of x = fl32(q s) by s is q or a
+        # float32 neighbour of q, and that residue is part of the float tensor the next QuantAct calibrates / ranges on
+        x_int = (x / pre_act_scaling_factor).double()
         acc = self._conv(x_int, wint.double(), None if bint is None else bint.double()).float()
         sf = s_b.view(1, -1, 1)
         return acc * sf, sf
