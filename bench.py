@@ -444,6 +444,8 @@ def run(args):
 
     alen = torch.full((BATCH,), SAMPLES, dtype=torch.int32, device=dev)
 
+    step_trace = [] if os.environ.get('QASR_BENCH_STEP_TRACE') else None   # (diagnostic) when each step finished
+
     def step(lane, i, gathered=None):
         k = i % lane['S']
         b = lane['bufs'][k]
@@ -457,8 +459,10 @@ def run(args):
               # mel front-end + encoder + decoder as one engine call (one hipGraph launch per step)
               _, tokens, _ = lane['engs'][k].forward_audio(lane['audio'][k], alen, fb, window, fe_plan, 0.97, 16, want_logp=False,
                                                          feats=b['fe'][0], feat_lens=b['fe'][1], out=b['out'])
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=bool(step_trace is not None))
             done.record(lane['streams'][k])
+            if step_trace is not None:
+                step_trace.append((i, k, done))
         if world > 1:
             # one communicator: the per-step gathers are issued in step order on the default stream, each behind its
             # step's compute stream; compute of later steps keeps running on the other streams
@@ -488,6 +492,8 @@ def run(args):
         ev0.record()                                             # (default stream, idle: the region's device-side origin)
         t0 = time.perf_counter()
         last = {}
+        if step_trace is not None:
+            step_trace.clear()
         for i in range(steps):
             last[i % S] = step(lane, i, gathered)
         t_enq = time.perf_counter() - t0
@@ -498,6 +504,9 @@ def run(args):
             ends.append(e_)
         torch.cuda.synchronize()
         log('streams finished at ' + ', '.join(f'{ev0.elapsed_time(e_):.2f}' for e_ in ends) + ' ms after the region began')
+        if step_trace is not None:
+            for k in range(S):
+                log(f'  stream {k}: steps finished at ' + ' '.join(f'{ev0.elapsed_time(e_):.2f}' for i_, k_, e_ in step_trace if k_ == k))
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
