@@ -154,7 +154,7 @@ void qasr_engine_destroy(qasr_engine* e);
  * Environment variables remain ONLY as A/B overrides for profiling runs of an unmodified caller, read once per create
  * call AFTER the options: QASR_TILE128=0|1 (128-frame tiles when tile_frames >= 64), QASR_RES_TILE128, QASR_DENSE_TILE128,
  * QASR_SEP_GEN=1|2, QASR_NO_FUSE, QASR_NO_FUSE_STEM, QASR_NO_FUSE_DEC, QASR_LEGACY_PW, QASR_UTT, QASR_WIDE_TILES,
- * QASR_PERSISTENT=0|1; QASR_SEP2_TUNE is a kernel-internal experiment knob (csrc/qasr_sep2_impl.h). */
+ * QASR_PERSISTENT=0|1, QASR_NO_FUSE_NORM; QASR_SEP2_TUNE is a kernel-internal experiment knob (csrc/qasr_sep2_impl.h). */
 typedef struct qasr_engine_opts {
   uint32_t struct_size;
   uint32_t debug;              /* bit 0: keep every tensor + int32 accumulators (parity hooks); bit 1: one HIP event per op */
@@ -173,7 +173,9 @@ typedef struct qasr_engine_opts {
   int32_t persistent;          /* runs of consecutive k_sep2 layers as ONE persistent launch (one work-group per utterance
                                   walks the layers and both time tiles: no kernel boundary, no inter-work-group exchange);
                                   meant for many steps in flight - a 32-utterance launch occupies 32 CUs */
-  int32_t reserved[3];
+  int32_t fuse_norm;           /* qasr_engine_forward_audio with the fused block 0: normalize_batch folded into k_stem from
+                                  per-tile sums k_mel writes (no k_norm launch; `feats` then holds the UN-normalised log-mel) */
+  int32_t reserved[2];
 } qasr_engine_opts;
 /* fills `o` with struct_size and the defaults (-1 / 0) */
 void qasr_engine_default_opts(qasr_engine_opts* o);
@@ -192,15 +194,19 @@ int qasr_engine_forward(qasr_engine* e, void* stream, const float* feats, const 
 /* The same with the mel front-end in front (qasr_frontend_mel_planned into the caller's `feats` [B][n_mels][T_pad] /
  * `feat_lens` [B] buffers, T_pad = qasr_frontend_frames(S, pad_to)): AudioToMelSpectrogramPreprocessor + encoder +
  * decoder of EncDecCTCModel.forward (ctc_models.py:383-406) as ONE call - and, with graph replay on, one hipGraph launch
- * per batch.  `frontend_plan`: a workspace filled by qasr_frontend_plan for this filterbank. */
+ * per batch.  `frontend_plan`: a workspace filled by qasr_frontend_plan for this filterbank.
+ * `feats` is working storage of the call: with qasr_engine_opts.fuse_norm (default on where block 0 runs as k_stem) it holds
+ * the log-mel BEFORE normalize_batch (features.py:53-67 runs inside k_stem); fuse_norm = 0 leaves the normalised features
+ * qasr_frontend_mel returns. */
 int qasr_engine_forward_audio(qasr_engine* e, void* stream, const float* audio, const int32_t* audio_lens, int B, int S,
                               const float* fb, const float* window, int n_mels, float preemph, int pad_to,
                               const void* frontend_plan, size_t plan_bytes, float* feats, int32_t* feat_lens, float* logp,
                               int32_t* tokens, int32_t* lens_out);
 int qasr_engine_out_frames(const qasr_engine* e, int T);
 int qasr_engine_num_ops(const qasr_engine* e);
-/* kernel launches of one forward of the current plan (encoder + decoder, without the two front-end launches of
- * qasr_engine_forward_audio): 80 for QuartzNet15x5 with the default options, 7 with `persistent`; -1 before the first forward */
+/* kernel launches of the last forward with the current plan: encoder + decoder (80 for QuartzNet15x5 with the default
+ * options, 7 with `persistent`) plus, after qasr_engine_forward_audio, the front-end's (k_mel; + k_norm when fuse_norm is
+ * off: 81 / 82); -1 before the first forward */
 int qasr_engine_num_launches(const qasr_engine* e);
 
 /* Parity hooks (debug engines only; synchronise the stream).  acc: int32 [B][cout][T_out] = the

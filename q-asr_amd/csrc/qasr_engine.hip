@@ -96,6 +96,11 @@ struct qasr_engine {
   std::vector<char> skip;              // per op: launched as part of the following op
   bool fuse_stem = true;               // block 0 (lengths, first-layer quantisation, strided depthwise, 1x1) in one launch (QASR_NO_FUSE_STEM=1: four)
   bool stem = false;                   // ... and the plan has that shape: ops 0..2 run as k_stem
+  bool fuse_norm = true;               // forward_audio: normalize_batch inside k_stem from k_mel's per-tile sums (qasr_engine_opts.fuse_norm)
+  double* norm_stats = nullptr;        // [B][tiles][n_mels][2]
+  size_t norm_stats_bytes = 0;
+  int norm_tiles = 0, norm_frames = 0; // of the forward being enqueued (0: the stem reads normalised features)
+  int fe_launches = 0;                 // front-end kernels of the last forward (forward_audio: k_mel [+ k_norm])
   const int32_t* cur_lens = nullptr;   // the caller's lengths of the current / last forward (k_stem derives every domain's from them)
   bool fuse_dec = true;                // decoder conv + log-softmax + argmax in one launch (QASR_NO_FUSE_DEC=1: two launches)
   std::vector<char> rq_skip;           // per op: REQUANT op served by the launch of an earlier REQUANT op of the same stored value
@@ -152,6 +157,10 @@ static void free_plan(qasr_engine* e) {
   e->time_tokens = nullptr;
   if (e->r32) (void)hipFree(e->r32);
   e->r32 = nullptr;
+  if (e->norm_stats) (void)hipFree(e->norm_stats);
+  e->norm_stats = nullptr;
+  e->norm_stats_bytes = 0;
+  e->norm_tiles = e->norm_frames = 0;
   for (auto& v : e->acc_dbg)
     for (auto p : v)
       if (p) (void)hipFree(p);
@@ -370,7 +379,7 @@ void qasr_engine_default_opts(qasr_engine_opts* o) {
   if (!o) return;
   memset(o, 0, sizeof *o);
   o->struct_size = (uint32_t)sizeof *o;
-  o->fuse_dw = o->fuse_stem = o->fuse_decoder = o->res_tile128 = o->dense_tile128 = -1;
+  o->fuse_dw = o->fuse_stem = o->fuse_decoder = o->res_tile128 = o->dense_tile128 = o->fuse_norm = -1;
 }
 
 // the `debug` bits of round 1 / 2 callers, as options
@@ -416,6 +425,7 @@ int qasr_engine_create_ex(const void* blob, size_t n, int device, const qasr_eng
   e->fuse = tri(o.fuse_dw, true);
   e->fuse_stem = tri(o.fuse_stem, true);
   e->fuse_dec = tri(o.fuse_decoder, true);
+  e->fuse_norm = tri(o.fuse_norm, true);
   e->legacy_pw = o.legacy_pw > 0;
   e->wide_tiles = o.tile_frames >= 64;
   e->tile128 = o.tile_frames == 128;
@@ -433,6 +443,7 @@ int qasr_engine_create_ex(const void* blob, size_t n, int device, const qasr_eng
   if (const char* g = getenv("QASR_RES_TILE128")) e->res_tile128 = atoi(g) != 0;
   if (const char* g = getenv("QASR_NO_FUSE_DEC")) e->fuse_dec = atoi(g) == 0;
   if (const char* g = getenv("QASR_NO_FUSE_STEM")) e->fuse_stem = atoi(g) == 0;
+  if (const char* g = getenv("QASR_NO_FUSE_NORM")) e->fuse_norm = atoi(g) == 0;
   if (const char* g = getenv("QASR_DENSE_TILE128")) e->dense_tile128 = atoi(g) != 0;
   if (const char* g = getenv("QASR_SEP_GEN")) e->sep_gen = atoi(g) == 1 ? 1 : 2;
   if (getenv("QASR_UTT")) e->use_utt = true;
@@ -522,7 +533,7 @@ int qasr_engine_num_ops(const qasr_engine* e) { return e ? (int)e->h.n_ops : -1;
 
 int qasr_engine_num_launches(const qasr_engine* e) {
   if (!e || !e->B || !e->mega_built) return -1;
-  int n = e->stem ? 0 : 1;                                   // (k_lens, which the stem absorbs)
+  int n = (e->stem ? 0 : 1) + e->fe_launches;               // (k_lens, which the stem absorbs; front-end of forward_audio)
   for (uint32_t oi = 0; oi < e->h.n_ops; ++oi) {
     if (e->mega_of[oi] >= 0) {
       n += oi == e->mega_runs[e->mega_of[oi]].first;
@@ -661,7 +672,7 @@ static int stem_launch(qasr_engine* e, hipStream_t s) {
   build_dw(e, 1, dw);
   build_sep(e, 2, pw);
   int rc = launch_stem(s, qi, dw, pw, (const qasr_domain_desc*)(e->dblob + e->h.domains_off), (int)e->h.n_domains, e->cur_lens,
-                       e->lens_all);
+                       e->lens_all, e->norm_tiles ? e->norm_stats : nullptr, e->norm_tiles, e->norm_frames);
   return rc ? fail(rc, "k_stem launch") : QASR_OK;
 }
 
@@ -887,8 +898,32 @@ static int forward_impl(qasr_engine* e, hipStream_t s, const FrontArgs* fe, floa
   e->tens[0].ptr = (void*)feats;
   e->cur_lens = lens;
   e->stem = e->fuse_stem && stem_shape(e);
+  // normalize_batch inside k_stem: k_mel leaves per-tile sums, no k_norm launch
+  const bool norm_in_stem = fe && e->stem && e->fuse_norm && fe->n_mels == (int)h.feat_in;
+  e->norm_tiles = e->norm_frames = 0;                        // (a forward on features hands k_stem normalised input)
+  e->fe_launches = fe ? (norm_in_stem ? 1 : 2) : 0;
+  if (norm_in_stem) {
+    e->norm_frames = 1 + fe->S / 160;
+    e->norm_tiles = (e->norm_frames + QASR_MEL_TILE - 1) / QASR_MEL_TILE;
+    const size_t need = frontend_stats_bytes(B, fe->S, fe->n_mels);
+    if (need > e->norm_stats_bytes) {                        // (a captured graph holds the old pointer)
+      if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+      e->gexec = nullptr;
+      e->gkey[0] = nullptr;
+      if (e->norm_stats) HIPCHK(hipFree(e->norm_stats));
+      e->norm_stats = nullptr;
+      e->norm_stats_bytes = 0;
+      HIPCHK(hipMalloc(&e->norm_stats, need));
+      e->norm_stats_bytes = need;
+    }
+  }
   auto enqueue = [&]() -> int {
-    if (fe) {                                                // mel front-end into the caller's feature / length buffers
+    if (fe && norm_in_stem) {
+      int nt = 0, nf = 0;
+      int rc = frontend_mel_stats(s, fe->audio, fe->audio_lens, B, fe->S, fe->fb, fe->window, fe->n_mels, fe->preemph, fe->pad_to,
+                                  feats, lens, fe->plan, fe->plan_bytes, e->norm_stats, &nt, &nf);
+      if (rc || nt != e->norm_tiles || nf != e->norm_frames) return fail(rc ? rc : QASR_ERR_ARG, "forward_audio: front-end (k_mel with statistics)");
+    } else if (fe) {                                         // mel front-end into the caller's feature / length buffers
       int rc = qasr_frontend_mel_planned(s, fe->audio, fe->audio_lens, B, fe->S, fe->fb, fe->window, fe->n_mels, fe->preemph,
                                          fe->pad_to, feats, lens, fe->plan, fe->plan_bytes);
       if (rc) return fail(rc, "forward_audio: front-end");

@@ -14,6 +14,7 @@
 // is rounded once to the float32 spectrum torch.stft would ideally return; everything after it (magnitude, square, mel
 // dot, log, normalisation) follows features.py in float32.  tests/test_gpu_model.py: <= 1e-4.
 #include "qasr_device.h"
+#include "qasr_internal.h"
 
 namespace qasr {
 
@@ -101,6 +102,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 #endif
 #define MEL_FPW 4                          /* frames per wave */
 #define MEL_FR (4 * MEL_FPW)               /* consecutive frames of one utterance per work-group (4 waves) */
+static_assert(MEL_FR == QASR_MEL_TILE, "k_stem combines k_mel's statistics per tile of QASR_MEL_TILE frames");
 #define MEL_NS (HOP * (MEL_FR - 1) + WIN)  /* signal samples under those frames' (centred, 320-tap) windows */
 #define MEL_NQ ((MEL_NS + 255) / 256)
 
@@ -146,7 +148,9 @@ __global__ void __launch_bounds__(256, 4) k_mel(const float* __restrict__ audio,
                                              const float* __restrict__ window, const int* __restrict__ hdr,
                                              const int* __restrict__ ranges, const int* __restrict__ goffs,
                                              const float* __restrict__ table, const double2* __restrict__ twg, int n_mels,
-                                             float preemph, int n_frames, int T_pad, float* __restrict__ out) {
+                                             float preemph, int n_frames, int T_pad, float* __restrict__ out,
+                                             const int32_t* __restrict__ audio_lens, double* __restrict__ stats,
+                                             int32_t* __restrict__ feat_lens) {
   __shared__ double2 zb[4][MEL_ZLEN];      // per wave: complex work buffer (padded, zpad)
   __shared__ float pw[4][NBIN + 3];        // per wave: power spectrum, [257..259] = 0
   __shared__ __attribute__((aligned(8))) float ys[MEL_NS];   // pre-emphasised signal under the windows, [0] <-> signal index 160 t0 - 160
@@ -297,6 +301,23 @@ __global__ void __launch_bounds__(256, 4) k_mel(const float* __restrict__ audio,
       const int ml = i / MEL_FR, fl = i - ml * MEL_FR;
       if (m0 + ml < n_mels && t0 + fl < n_frames) out[((size_t)b * n_mels + m0 + ml) * T_pad + t0 + fl] = ob[ml][fl];
     }
+    // normalisation fused into the consumer (k_stem): this tile's share of normalize_batch's statistics per mel bin
+    // (features.py:53-67) - sum and sum of squared deviations from the tile mean over the valid frames, float64
+    if (stats && tid < 64 && m0 + tid < n_mels) {
+      const int seq = (audio_lens[b] + HOP - 1) / HOP;
+      const int nv = max(0, min(min(seq, n_frames) - t0, MEL_FR));
+      double sum = 0.0, m2 = 0.0;
+      for (int fl = 0; fl < nv; ++fl) sum += (double)ob[tid][fl];
+      const double mu = nv ? sum / (double)nv : 0.0;
+      for (int fl = 0; fl < nv; ++fl) {
+        const double d = (double)ob[tid][fl] - mu;
+        m2 += d * d;
+      }
+      double* st = stats + (((size_t)b * gridDim.x + blockIdx.x) * n_mels + m0 + tid) * 2;
+      st[0] = sum;
+      st[1] = m2;
+    }
+    if (feat_lens && blockIdx.x == 0 && tid == 0) feat_lens[b] = (audio_lens[b] + HOP - 1) / HOP;   // get_seq_len (features.py:327-328)
     __syncthreads();
   }
 }
@@ -397,11 +418,42 @@ int qasr_frontend_mel_planned(void* stream, const float* audio, const int32_t* a
   hipLaunchKernelGGL(qasr::k_mel, dim3((n_frames + MEL_FR - 1) / MEL_FR, B), dim3(256), 0, s, audio, B, S, fb, window,
                      (const int*)ws, (const int*)(ws + ws_ranges(n_mels)), (const int*)(ws + ws_offs(n_mels)),
                      (const float*)(ws + ws_table(n_mels)), (const double2*)(ws + ws_tw(n_mels)), n_mels, preemph, n_frames,
-                     T_pad, feats);
+                     T_pad, feats, nullptr, nullptr, nullptr);
   hipLaunchKernelGGL(qasr::k_norm, dim3(B * n_mels), dim3(64), 0, s, feats, audio_lens, n_mels, n_frames, T_pad,
                      feat_lens);
   return hipGetLastError() == hipSuccess ? QASR_OK : QASR_ERR_HIP;
 }
+
+}  // extern "C"
+
+namespace qasr {
+size_t frontend_stats_bytes(int B, int S, int n_mels) {
+  const int n_frames = 1 + S / HOP;
+  return (size_t)B * ((n_frames + MEL_FR - 1) / MEL_FR) * n_mels * 2 * sizeof(double);
+}
+// k_mel alone: un-normalised log-mel into `feats`, feat_lens, and per (utterance, 16-frame tile, mel bin) the partial
+// statistics k_stem combines into normalize_batch's mean / std (the engine's forward_audio with the fused stem)
+int frontend_mel_stats(hipStream_t s, const float* audio, const int32_t* audio_lens, int B, int S, const float* fb,
+                       const float* window, int n_mels, float preemph, int pad_to, float* feats, int32_t* feat_lens,
+                       const void* workspace, size_t workspace_bytes, double* stats, int* n_tiles, int* n_frames_out) {
+  if (!audio || !audio_lens || !fb || !window || !feats || !feat_lens || !stats || B <= 0 || S <= NFFT / 2 || n_mels <= 0 ||
+      !workspace || workspace_bytes < qasr_frontend_workspace_bytes(B, S, n_mels) || ((size_t)workspace & 15))
+    return QASR_ERR_ARG;
+  const int n_frames = 1 + S / HOP;
+  const int T_pad = qasr_frontend_frames(S, pad_to);
+  const char* ws = (const char*)workspace;
+  const int nt = (n_frames + MEL_FR - 1) / MEL_FR;
+  hipLaunchKernelGGL(k_mel, dim3(nt, B), dim3(256), 0, s, audio, B, S, fb, window, (const int*)ws,
+                     (const int*)(ws + ws_ranges(n_mels)), (const int*)(ws + ws_offs(n_mels)),
+                     (const float*)(ws + ws_table(n_mels)), (const double2*)(ws + ws_tw(n_mels)), n_mels, preemph, n_frames,
+                     T_pad, feats, audio_lens, stats, feat_lens);
+  *n_tiles = nt;
+  *n_frames_out = n_frames;
+  return hipGetLastError() == hipSuccess ? QASR_OK : QASR_ERR_HIP;
+}
+}  // namespace qasr
+
+extern "C" {
 
 int qasr_frontend_mel(void* stream, const float* audio, const int32_t* audio_lens, int B, int S, const float* fb,
                       const float* window, int n_mels, float preemph, int pad_to, float* feats, int32_t* feat_lens,

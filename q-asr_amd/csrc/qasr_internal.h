@@ -144,8 +144,15 @@ void launch_requant(hipStream_t s, const RequantP& p);
 void launch_logsoftmax(hipStream_t s, const float* logits, float* logp, int32_t* tokens, int rows, int ncls);
 // qasr_stem.hip: lengths + first-layer QuantAct + strided depthwise conv + 1x1 conv of block 0 as one launch
 bool stem_supported(const QuantInP& qi, const DwP& dw, const SepP& pw);
+// stats != nullptr: x holds un-normalised log-mel and normalize_batch runs inside (per-tile sums from frontend_mel_stats)
 int launch_stem(hipStream_t s, const QuantInP& qi, const DwP& dw, const SepP& pw, const qasr_domain_desc* doms, int n_domains,
-                const int32_t* lens_in, int32_t* lens_all);
+                const int32_t* lens_in, int32_t* lens_all, const double* stats = nullptr, int n_stat_tiles = 0, int n_frames = 0);
+// qasr_frontend.hip: k_mel alone (un-normalised log-mel, feat_lens, per-tile statistics [B][tiles][n_mels][2] f64)
+#define QASR_MEL_TILE 16
+size_t frontend_stats_bytes(int B, int S, int n_mels);
+int frontend_mel_stats(hipStream_t s, const float* audio, const int32_t* audio_lens, int B, int S, const float* fb,
+                       const float* window, int n_mels, float preemph, int pad_to, float* feats, int32_t* feat_lens,
+                       const void* workspace, size_t workspace_bytes, double* stats, int* n_tiles, int* n_frames);
 // qasr_decoder.hip: the decoder's 1x1 conv + log_softmax + argmax (+ the encoded lengths) as one launch
 bool decoder_fusable(const SepP& p);
 int launch_decoder(hipStream_t s, const SepP& p, float* logp, int32_t* tokens, int32_t* lens_out, bool keep_logits);

@@ -48,8 +48,9 @@ void sep_kernel_label(const SepP& p, char* buf, size_t cap) {
     return;
   }
   if (sep2_takes(p)) {
-    snprintf(buf, cap, p.K > 0 && p.dilation == 2 ? "k_sep2<%d, %d, %d, %d, %s, %d, 2>" : "k_sep2<%d, %d, %d, %d, %s, %d>", p.K, p.cin_pad >> 7,
-             (p.e.flags & QASR_F_RESADD) ? p.panes[0].cin_pad >> 7 : 0, (p.e.cout + 255) / 256, dbg ? "true" : "false", sep2_tile(p));
+    snprintf(buf, cap, "k_sep2<%d, %d, %d, %d, %s, %d, %d>", p.K, p.cin_pad >> 7,
+             (p.e.flags & QASR_F_RESADD) ? p.panes[0].cin_pad >> 7 : 0, (p.e.cout + 255) / 256, dbg ? "true" : "false", sep2_tile(p),
+             p.K > 0 ? p.dilation : 1);
     return;
   }
   snprintf(buf, cap, "k_sep<%d, %d, %d, %s, %d>", p.K, p.K > 0 ? p.dilation : 1, sep_epilogue_class(p), dbg ? "true" : "false",

@@ -1,6 +1,7 @@
 // Fused stem: block 0 of a time-channel-separable encoder (QuartzNet: examples/asr/conf/quartznet_15x5.yaml:55-66 -
 // depthwise k33 stride 2 on the 64 mel features, 1x1 64 -> 256, BN, ReLU) as ONE launch instead of four:
 //   lengths of every time domain      MaskedConv1d.get_seq_len, jasper.py:170-173            (was k_lens)
+//   [normalize_batch                  features.py:53-67, from k_mel's per-tile sums           (was k_norm; forward_audio)]
 //   first-layer QuantAct              quant_modules.py:180-184: clamp(round(fl32(1/s) x))     (was k_quant_in)
 //   strided depthwise QuantConv1d     quant_modules.py:301-305 + the 1x1 conv's QuantAct      (was k_dw_generic)
 //   1x1 QuantConv1d + consumers' QuantAct                                                     (was k_sep<0, 1, 1>)
@@ -44,6 +45,11 @@ struct StemP {
   const qasr_domain_desc* doms;
   int n_domains;
   int32_t* lens_all;        // [n_domains][B]
+  // normalize_batch folded in (features.py:53-67; forward_audio): x holds k_mel's un-normalised log-mel and stats its
+  // per-tile sums [B][n_stat_tiles][C][2] (sum, squared deviations from the tile mean) over 16-frame tiles; nullptr: x is
+  // normalised already
+  const double* stats;
+  int n_stat_tiles, n_frames;
 };
 
 __device__ __forceinline__ int stem_out_len(int l, int kernel, int stride, int dilation, int padding) {
@@ -74,7 +80,38 @@ __global__ void __launch_bounds__(STEM_NT) k_stem(StemP p) {
   const int len_mid = stem_out_len(len_in, p.K, 2, 1, p.padding);
   // ---- first-layer QuantAct of the window: input frame of byte i = 2 t0 - padding + i
   const int tin0 = 2 * t0 - p.padding;
-  const int lim_in = min(len_in, p.Tx);
+  const int lim_in = min(len_in, p.stats ? p.n_frames : p.Tx);
+  __shared__ float s_mean[STEM_CMAX], s_sd[STEM_CMAX];
+  if (p.stats) {
+    // mean / unbiased std of every mel bin over the utterance's valid frames from the tiles' float64 partial sums:
+    // sum_t (x - m)^2 = sum_tiles [M2_i + n_i (mean_i - m)^2] with m the float32 mean the reference subtracts
+    // (8 threads per bin, fixed order: the result does not depend on which work-group computes it)
+    const int c = tid >> 3, j = tid & 7;
+    const int n = lim_in;
+    const double* st = p.stats + ((size_t)b * p.n_stat_tiles * p.C + min(c, p.C - 1)) * 2;
+    double sum = 0.0;
+    for (int i = j; i < p.n_stat_tiles; i += 8) sum += st[(size_t)i * p.C * 2];
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    sum += __shfl_xor(sum, 4);
+    const float mean = (float)(sum / (double)n);
+    double m2 = 0.0;
+    for (int i = j; i < p.n_stat_tiles; i += 8) {
+      const int ni = max(0, min(n - QASR_MEL_TILE * i, QASR_MEL_TILE));
+      if (ni > 0) {
+        const double d = st[(size_t)i * p.C * 2] / (double)ni - (double)mean;
+        m2 += st[(size_t)i * p.C * 2 + 1] + (double)ni * d * d;
+      }
+    }
+    m2 += __shfl_xor(m2, 1);
+    m2 += __shfl_xor(m2, 2);
+    m2 += __shfl_xor(m2, 4);
+    if (j == 0 && c < p.C) {
+      s_mean[c] = mean;
+      s_sd[c] = (float)sqrt(m2 / (double)(n - 1)) + 1e-5f;     // torch.std (unbiased) + CONSTANT (features.py:63-65)
+    }
+    __syncthreads();
+  }
   {
     // 64 channels x 28 dwords = 1792 items over 512 threads: all of a thread's loads leave before the first use
     // (unconditional, from clamped frame indices; a load under a branch is waited for on the spot)
@@ -98,7 +135,8 @@ __global__ void __launch_bounds__(STEM_NT) k_stem(StemP p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int ti = tin0 + 4 * i4 + k;
-          const float xk = (ti >= 0 && ti < lim_in) ? xv[u][k] : 0.0f;      // zero padding and MaskedConv1d's mask
+          float xk = (ti >= 0 && ti < lim_in) ? xv[u][k] : 0.0f;            // zero padding and MaskedConv1d's mask
+          if (p.stats && ti >= 0 && ti < lim_in) xk = __fdiv_rn(__fsub_rn(xk, s_mean[c]), s_sd[c]);
           v[k] = (int)fminf(fmaxf(rintf(__fmul_rn(p.inv_scale, xk)), (float)p.qlo), (float)p.qhi);
         }
         *(unsigned*)(xq + c * STEM_XP + 4 * i4) = pack4(v[0], v[1], v[2], v[3]);
@@ -203,7 +241,7 @@ bool stem_supported(const QuantInP& qi, const DwP& dw, const SepP& pw) {
 }
 
 int launch_stem(hipStream_t s, const QuantInP& qi, const DwP& dw, const SepP& pw, const qasr_domain_desc* doms, int n_domains,
-                const int32_t* lens_in, int32_t* lens_all) {
+                const int32_t* lens_in, int32_t* lens_all, const double* stats, int n_stat_tiles, int n_frames) {
   const EpiP& e = pw.e;
   if (!stem_supported(qi, dw, pw) || !qi.x || !lens_in || !lens_all || !doms) return QASR_ERR_UNSUPPORTED;
   StemP p{};
@@ -214,6 +252,8 @@ int launch_stem(hipStream_t s, const QuantInP& qi, const DwP& dw, const SepP& pw
   p.w = pw.w, p.bias = pw.bias, p.cin_pad = pw.cin_pad;
   p.e = e;
   p.doms = doms, p.n_domains = n_domains, p.lens_all = lens_all;
+  p.stats = stats, p.n_stat_tiles = n_stat_tiles, p.n_frames = n_frames;
+  if (stats && (n_stat_tiles < 1 || n_frames < 1 || n_frames > qi.T)) return QASR_ERR_ARG;
   hipLaunchKernelGGL(k_stem, dim3(e.B, e.Tp / STEM_TT), dim3(STEM_NT), 0, s, p);
   return QASR_OK;
 }

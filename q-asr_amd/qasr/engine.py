@@ -42,8 +42,8 @@ class EngineOpts(C.Structure):
     """qasr_engine_opts (include/qasr.h): the launch-plan choices of one engine."""
     _fields_ = ([('struct_size', C.c_uint32), ('debug', C.c_uint32)] +
                 [(n, C.c_int32) for n in ('tile_frames', 'sep_gen', 'fuse_dw', 'fuse_stem', 'fuse_decoder', 'graph',
-                                          'whole_utterance', 'res_tile128', 'dense_tile128', 'legacy_pw', 'persistent')] +
-                [('reserved', C.c_int32 * 3)])
+                                          'whole_utterance', 'res_tile128', 'dense_tile128', 'legacy_pw', 'persistent', 'fuse_norm')] +
+                [('reserved', C.c_int32 * 2)])
 
 
 class QasrError(RuntimeError):
@@ -125,7 +125,7 @@ class Engine:
 
     def __init__(self, blob: bytes, device=0, debug=False, timing=False, whole_utterance=False, wide_tiles=False,
                  graph=False, tile=None, sep_gen=None, fuse_dw=None, fuse_stem=None, fuse_decoder=None, res_tile128=None,
-                 dense_tile128=None, persistent=False):
+                 dense_tile128=None, persistent=False, fuse_norm=None):
         """Options = qasr_engine_opts (include/qasr.h).  tile: frames per work-group (32 / 64 / 128; `wide_tiles=True` is the
         older spelling of 128); None leaves a choice at the engine's default."""
         lib = load_library()
@@ -143,7 +143,7 @@ class Engine:
         o.tile_frames = int(tile) if tile else (128 if wide_tiles else 32)
         o.sep_gen = int(sep_gen or 0)
         for name, v in (('fuse_dw', fuse_dw), ('fuse_stem', fuse_stem), ('fuse_decoder', fuse_decoder),
-                        ('res_tile128', res_tile128), ('dense_tile128', dense_tile128)):
+                        ('res_tile128', res_tile128), ('dense_tile128', dense_tile128), ('fuse_norm', fuse_norm)):
             if v is not None:
                 setattr(o, name, int(bool(v)))
         o.graph, o.whole_utterance, o.persistent = int(bool(graph)), int(bool(whole_utterance)), int(bool(persistent))

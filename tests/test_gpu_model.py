@@ -166,10 +166,13 @@ def test_cli_inference_dynamic(tmp_path):
     assert 'path: dynamic device path (HIP)' in out.stdout
 
 
-def test_forward_audio_equals_frontend_plus_forward(golden_dir):
+@pytest.mark.parametrize('fuse_norm', [True, False])
+def test_forward_audio_equals_frontend_plus_forward(golden_dir, fuse_norm):
     """qasr_engine_forward_audio (front-end inside the engine call, one hipGraph launch per batch) against
     qasr_frontend_mel followed by qasr_engine_forward: identical features, log-probs, tokens and lengths - on the direct
-    launches of the first call, on the capture and on the replays."""
+    launches of the first call, on the capture and on the replays.  fuse_norm (the default): normalize_batch runs inside
+    k_stem from k_mel's per-tile float64 sums, one launch fewer; `feats` then holds the log-mel before normalisation and
+    everything behind it must still be identical (ragged lengths down to 3 frames, a length that ends inside a tile)."""
     from qasr import engine, pack
     d = np.load(os.path.join(golden_dir, 'net_quartznet_w8a8.npz'))
     meta = json.loads(str(d['meta']))
@@ -181,8 +184,9 @@ def test_forward_audio_equals_frontend_plus_forward(golden_dir):
     win = torch.hann_window(320, periodic=False).cuda()
     B, S = 4, 40000
     audio = torch.from_numpy(synth.make_audio(B, S, seed=5)).cuda()
-    alen = torch.tensor([S, S - 7001, S - 16000, 9000], dtype=torch.int32).cuda()
-    e1, e2 = engine.Engine(blob, 0, graph=True), engine.Engine(blob, 0, graph=True)
+    alen = torch.tensor([S, S - 7001, S - 16000, 400], dtype=torch.int32).cuda()
+    e1, e2 = engine.Engine(blob, 0, graph=True), engine.Engine(blob, 0, graph=True, fuse_norm=fuse_norm)
+    assert e2.opts.fuse_norm == int(fuse_norm)
     feats, flen = engine.frontend_mel(audio, alen, fb, win, 0.97, 16)
     lp0, tk0, el0 = e1.forward(feats, flen)
     plan = engine.frontend_plan(fb)
@@ -198,8 +202,17 @@ def test_forward_audio_equals_frontend_plus_forward(golden_dir):
         with torch.cuda.stream(st):
             lp, tk, el = e2.forward_audio(audio, alen, fb, win, plan, 0.97, 16, feats=fbuf, feat_lens=lbuf, out=out)
         torch.cuda.synchronize()
-        assert torch.equal(fbuf, feats) and torch.equal(lbuf, flen), call
+        assert torch.equal(lbuf, flen), call
+        if fuse_norm:                                            # un-normalised log-mel: normalising it here gives the features
+            for b_ in range(B):
+                n = int(flen[b_])
+                x = fbuf[b_, :, :n].double()
+                want = (x - x.mean(1, keepdim=True).float().double()) / (x.std(1, keepdim=True).float().double() + 1e-5)
+                torch.testing.assert_close(want.float(), feats[b_, :, :n], rtol=1e-5, atol=1e-5)
+        else:
+            assert torch.equal(fbuf, feats), call
         assert torch.equal(lp, lp0) and torch.equal(tk, tk0) and torch.equal(el, el0), call
+    assert e2.num_launches() == e1.num_launches() + (1 if fuse_norm else 2), (e1.num_launches(), e2.num_launches())
     e1.close()
     e2.close()
 

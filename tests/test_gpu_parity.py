@@ -382,8 +382,8 @@ def test_device_quantile_matches_torch_cpu(eng):
 @pytest.mark.parametrize('family', KERNEL_FAMILIES, ids=KERNEL_IDS)
 def test_odd_sizes_against_oracle(eng, golden_dir, family):
     """Edge shapes the reference's MaskedConv1d handles (jasper.py:170-183): a single short utterance, lengths of
-    1 frame, lengths that are not multiples of any tile, T beyond one 256-frame window, every utterance shorter
-    than the padded batch.  Tokens and integer log-prob inputs must equal the oracle on the valid frames."""
+    1 frame and of 0 frames (all of its output is masked, enc_len 0), lengths that are not multiples of any tile, T beyond
+    one 256-frame window, every utterance shorter than the padded batch.  Tokens and integer log-prob inputs must equal the oracle on the valid frames."""
     from oracle import int_oracle as O
     d, meta = _load(golden_dir, 'net_miniq_w8a8')
     cfg = _cfg('net_miniq_w8a8')
@@ -392,7 +392,7 @@ def test_odd_sizes_against_oracle(eng, golden_dir, family):
     net = O.OracleNet(topology.conv_plan(cfg), cfg, sd, d['act_min'], d['act_max'], 8, 8)
     e = eng.Engine(blob, 0, **family)
     cases = [(1, 16, [16]), (1, 33, [33]), (3, 40, [1, 17, 40]), (2, 70, [2, 69]), (2, 600, [600, 301]),
-             (5, 130, [129, 64, 65, 1, 128]), (4, 96, [50, 50, 50, 50])]
+             (5, 130, [129, 64, 65, 1, 128]), (4, 96, [50, 50, 50, 50]), (3, 40, [0, 17, 40]), (2, 48, [0, 0])]
     for B, T, lens in cases:
         x = synth.make_features(B, cfg.feat_in, T, 100 + T)
         want = net.forward(x, lens)
@@ -403,6 +403,10 @@ def test_odd_sizes_against_oracle(eng, golden_dir, family):
             n = int(want['enc_len'][b])
             assert np.array_equal(tok[b, :n], want['tokens'][b, :n]), (B, T, lens, b)
             np.testing.assert_allclose(logp[b, :n], want['log_probs'][b, :n], rtol=1e-4, atol=5e-5)
+    # an empty batch or zero frames is an argument error at the boundary, not a launch with an empty grid
+    for B, T in ((0, 40), (2, 0)):
+        with pytest.raises(eng.QasrError):
+            e.forward(torch.zeros(B, cfg.feat_in, T, device='cuda'), torch.zeros(B, dtype=torch.int32))
     e.close()
 
 
@@ -520,7 +524,7 @@ def test_quartznet_t500_every_accumulator(eng, oracle_quartznet_t500, family):
     labels = e.op_labels()
     if family.get('gen') == 2:
         assert sum(l.startswith('k_sep2<') for l in labels) >= 70, labels      # the new kernel is what runs
-        want_tt = '128>' if family.get('tile128') == 1 else ('64>' if family.get('wide_tiles') else '32>')
+        want_tt = '128, 1>' if family.get('tile128') == 1 else ('64, 1>' if family.get('wide_tiles') else '32, 1>')
         assert sum(l.startswith('k_sep2<') and l.endswith(want_tt) for l in labels) >= 50, (want_tt, labels)
     else:
         assert not any(l.startswith('k_sep2<') for l in labels)
@@ -567,7 +571,7 @@ def test_production_engine_full_size_against_oracle(eng, oracle_full_size, opts)
     torch.cuda.synchronize()
     labels = e.op_labels()
     assert not any('true' in l for l in labels), labels        # no debug instantiation anywhere
-    tt = f", {opts['tile']}>"
+    tt = f", {opts['tile']}, 1>"
     assert sum(l.startswith('k_sep2<') and l.endswith(tt) for l in labels) >= 60, labels
     # QuartzNet15x5: ~80 launches layer by layer; persistent: stem, blocks 1-15 as ONE launch, block 16, block 17, decoder
     n_launch = e.num_launches()
