@@ -231,7 +231,8 @@ def dominant_kernel_roofline(eng, cfg, meta, ms, B, T):
     # the fused depthwise taps run on the matrix cores too (v_mfma_i32_4x4x4), so they count towards the MFMA bound
     t_mfma, t_hbm = (mfma + vdot) / n / PEAK_INT8_OPS, byts / n / PEAK_HBM
     serial = float(sum(ms))
-    tt = int(lab.rstrip('>').split(',')[-1]) if lab.startswith('k_sep') else 0   # frames per work-group (last template arg)
+    # frames per work-group: k_sep2<K, NG, NGP, NP, DBG, TT, DIL> / k_sep<K, DIL, EP, DBG, TT>
+    tt = int(lab.rstrip('>').split(',')[-2 if lab.startswith('k_sep2<') else -1]) if lab.startswith('k_sep') else 0
     out = {'kernel': 'qasr::' + lab, 'launches_per_step': n, 'avg_launch_us': 1e6 * t, '_ops': ops_l,
            '_wgs': B * (-(-T // tt)) if tt else None,
            'share_of_step_device_time': tot[lab] / serial,

@@ -82,36 +82,6 @@ __global__ void __launch_bounds__(STEM_NT) k_stem(StemP p) {
   const int tin0 = 2 * t0 - p.padding;
   const int lim_in = min(len_in, p.stats ? p.n_frames : p.Tx);
   __shared__ float s_mean[STEM_CMAX], s_sd[STEM_CMAX];
-  if (p.stats) {
-    // mean / unbiased std of every mel bin over the utterance's valid frames from the tiles' float64 partial sums:
-    // sum_t (x - m)^2 = sum_tiles [M2_i + n_i (mean_i - m)^2] with m the float32 mean the reference subtracts
-    // (8 threads per bin, fixed order: the result does not depend on which work-group computes it)
-    const int c = tid >> 3, j = tid & 7;
-    const int n = lim_in;
-    const double* st = p.stats + ((size_t)b * p.n_stat_tiles * p.C + min(c, p.C - 1)) * 2;
-    double sum = 0.0;
-    for (int i = j; i < p.n_stat_tiles; i += 8) sum += st[(size_t)i * p.C * 2];
-    sum += __shfl_xor(sum, 1);
-    sum += __shfl_xor(sum, 2);
-    sum += __shfl_xor(sum, 4);
-    const float mean = (float)(sum / (double)n);
-    double m2 = 0.0;
-    for (int i = j; i < p.n_stat_tiles; i += 8) {
-      const int ni = max(0, min(n - QASR_MEL_TILE * i, QASR_MEL_TILE));
-      if (ni > 0) {
-        const double d = st[(size_t)i * p.C * 2] / (double)ni - (double)mean;
-        m2 += st[(size_t)i * p.C * 2 + 1] + (double)ni * d * d;
-      }
-    }
-    m2 += __shfl_xor(m2, 1);
-    m2 += __shfl_xor(m2, 2);
-    m2 += __shfl_xor(m2, 4);
-    if (j == 0 && c < p.C) {
-      s_mean[c] = mean;
-      s_sd[c] = (float)sqrt(m2 / (double)(n - 1)) + 1e-5f;     // torch.std (unbiased) + CONSTANT (features.py:63-65)
-    }
-    __syncthreads();
-  }
   {
     // 64 channels x 28 dwords = 1792 items over 512 threads: all of a thread's loads leave before the first use
     // (unconditional, from clamped frame indices; a load under a branch is waited for on the spot)
@@ -125,6 +95,50 @@ __global__ void __launch_bounds__(STEM_NT) k_stem(StemP p) {
       const float* row = p.x + ((size_t)b * p.C + c) * p.Tx;
 #pragma unroll
       for (int k = 0; k < 4; ++k) xv[u][k] = row[min(max(tin0 + 4 * i4 + k, 0), p.Tx - 1)];
+    }
+    // (the window's loads are in flight while the statistics are combined)
+    if (p.stats) {
+      // mean / unbiased std of every mel bin over the utterance's valid frames from the tiles' float64 partial sums:
+      // sum_t (x - m)^2 = sum_tiles [M2_i + n_i (mean_i - m)^2] with m the float32 mean the reference subtracts
+      // (8 threads per bin, fixed order: the result does not depend on which work-group computes it)
+      const int c = tid >> 3, j = tid & 7;
+      const int n = lim_in;
+      const double* st = p.stats + ((size_t)b * p.n_stat_tiles * p.C + min(c, p.C - 1)) * 2;
+      constexpr int NC = 4;                                    // tiles per thread kept in registers (32 tiles = 5 s of audio)
+      double2 sv[NC];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const int i = j + 8 * q;
+        sv[q] = *(const double2*)(st + (size_t)min(i, p.n_stat_tiles - 1) * p.C * 2);
+        if (i >= p.n_stat_tiles) sv[q] = make_double2(0.0, 0.0);
+      }
+      double sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) sum += sv[q].x;
+      for (int i = j + 8 * NC; i < p.n_stat_tiles; i += 8) sum += st[(size_t)i * p.C * 2];
+      sum += __shfl_xor(sum, 1);
+      sum += __shfl_xor(sum, 2);
+      sum += __shfl_xor(sum, 4);
+      const float mean = (float)(sum / (double)n);
+      double m2 = 0.0;
+      auto tile_term = [&](int i, double s_i, double m2_i) {
+        const int ni = max(0, min(n - QASR_MEL_TILE * i, QASR_MEL_TILE));
+        if (ni > 0) {
+          const double d = s_i / (double)ni - (double)mean;
+          m2 += m2_i + (double)ni * d * d;
+        }
+      };
+#pragma unroll
+      for (int q = 0; q < NC; ++q) tile_term(j + 8 * q, sv[q].x, sv[q].y);
+      for (int i = j + 8 * NC; i < p.n_stat_tiles; i += 8) tile_term(i, st[(size_t)i * p.C * 2], st[(size_t)i * p.C * 2 + 1]);
+      m2 += __shfl_xor(m2, 1);
+      m2 += __shfl_xor(m2, 2);
+      m2 += __shfl_xor(m2, 4);
+      if (j == 0 && c < p.C) {
+        s_mean[c] = mean;
+        s_sd[c] = (float)sqrt(m2 / (double)(n - 1)) + 1e-5f;     // torch.std (unbiased) + CONSTANT (features.py:63-65)
+      }
+      __syncthreads();
     }
 #pragma unroll
     for (int u = 0; u < NI; ++u) {

@@ -166,13 +166,14 @@ def test_cli_inference_dynamic(tmp_path):
     assert 'path: dynamic device path (HIP)' in out.stdout
 
 
-@pytest.mark.parametrize('fuse_norm', [True, False])
-def test_forward_audio_equals_frontend_plus_forward(golden_dir, fuse_norm):
+@pytest.mark.parametrize('fuse_norm,S', [(True, 40000), (False, 40000), (True, 100000)])
+def test_forward_audio_equals_frontend_plus_forward(golden_dir, fuse_norm, S):
     """qasr_engine_forward_audio (front-end inside the engine call, one hipGraph launch per batch) against
     qasr_frontend_mel followed by qasr_engine_forward: identical features, log-probs, tokens and lengths - on the direct
     launches of the first call, on the capture and on the replays.  fuse_norm (the default): normalize_batch runs inside
     k_stem from k_mel's per-tile float64 sums, one launch fewer; `feats` then holds the log-mel before normalisation and
-    everything behind it must still be identical (ragged lengths down to 3 frames, a length that ends inside a tile)."""
+    everything behind it must still be identical (ragged lengths down to 3 frames, a length that ends inside a tile; 100000
+    samples = 40 statistics tiles, more than a thread of k_stem keeps in registers)."""
     from qasr import engine, pack
     d = np.load(os.path.join(golden_dir, 'net_quartznet_w8a8.npz'))
     meta = json.loads(str(d['meta']))
@@ -182,7 +183,7 @@ def test_forward_audio_equals_frontend_plus_forward(golden_dir, fuse_norm):
     from qasr import melbank
     fb = torch.from_numpy(melbank.mel_filterbank(16000, 512, 64, 0.0, 8000.0).astype(np.float32)).cuda().contiguous()
     win = torch.hann_window(320, periodic=False).cuda()
-    B, S = 4, 40000
+    B = 4
     audio = torch.from_numpy(synth.make_audio(B, S, seed=5)).cuda()
     alen = torch.tensor([S, S - 7001, S - 16000, 400], dtype=torch.int32).cuda()
     e1, e2 = engine.Engine(blob, 0, graph=True), engine.Engine(blob, 0, graph=True, fuse_norm=fuse_norm)
