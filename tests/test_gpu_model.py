@@ -279,3 +279,19 @@ def test_distill_on_gpu_matches_reference_fixture(golden_dir):
     np.testing.assert_allclose(np.array(hist), d['losses'], rtol=1e-3)
     got = np.stack([t.cpu().numpy() for t in out])
     assert np.mean(np.abs(got - d['refined']) <= 2e-3) > 0.999, float(np.abs(got - d['refined']).max())
+
+
+def test_bench_exchange_steps_on_a_one_rank_rccl_communicator():
+    """The N-GPU exchange steps of bench.py (blob broadcast, per-step token gather to rank 0, max-over-ranks
+    all-reduce, rank census) executed through torch.distributed's "nccl" backend = RCCL on the one GPU of this box
+    (QASR_BENCH_FORCE_DIST=1: a communicator of one rank makes the same calls, on the device, as the 8-rank run)."""
+    env = dict(os.environ, QASR_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '8', '--warmup', '2',
+                          '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['n_ranks_seen'] == 1 and line['steps'] == 8
+    assert 'RCCL blob broadcast + token gather' in line['config']['parallelism']
+    assert line['value'] > 0
