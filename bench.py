@@ -447,8 +447,7 @@ def run(args):
         bufs = [dict(fe=(torch.empty(BATCH, 64, T_pad, device=dev), torch.empty(BATCH, dtype=torch.int32, device=dev),
                          torch.empty(max(lib_ws, 16), dtype=torch.uint8, device=dev)),
                      out=(None, torch.empty(BATCH, T_out, dtype=torch.int32, device=dev),
-                          torch.empty(BATCH, dtype=torch.int32, device=dev)),
-                     gathered=None) for _ in range(S)]
+                          torch.empty(BATCH, dtype=torch.int32, device=dev))) for _ in range(S)]
         return dict(S=S, engs=engs, streams=streams, audio=audio, bufs=bufs, T_out=T_out)
 
     alen = torch.full((BATCH,), SAMPLES, dtype=torch.int32, device=dev)
@@ -459,8 +458,6 @@ def run(args):
         k = i % lane['S']
         b = lane['bufs'][k]
         with torch.cuda.stream(lane['streams'][k]):
-            if b['gathered'] is not None:                    # the gather of this buffer set's previous step read `tokens`
-                lane['streams'][k].wait_event(b['gathered'])
             if os.environ.get('QASR_BENCH_SPLIT_FE'):            # (A/B) front-end as its own two launches in front of the graph
                 feats, flen = engine.frontend_mel(lane['audio'][k], alen, fb, window, 0.97, 16, out=b['fe'], plan=fe_plan)
                 _, tokens, _ = lane['engs'][k].forward(feats, flen, want_logp=False, out=b['out'])
@@ -473,13 +470,17 @@ def run(args):
             if step_trace is not None:
                 step_trace.append((i, k, done))
         if use_dist:
-            # one communicator: the per-step gathers are issued in step order on the default stream, each behind its
-            # step's compute stream; compute of later steps keeps running on the other streams
-            cur = torch.cuda.current_stream()
-            cur.wait_event(done)
-            qdist.gather_tokens(tokens if backend == 'nccl' else tokens.cpu(), 0, gathered)
-            b['gathered'] = torch.cuda.Event()
-            b['gathered'].record(cur)
+            # Exchange step: the step's tokens go to rank 0 through the one communicator, in step order, issued
+            # ON THE STEP'S OWN COMPUTE STREAM: same-stream order puts the gather behind the step that produced the tokens
+            # and in front of the step that overwrites them (4 steps later), so no event of this file's making is needed;
+            # the other 3 streams keep computing while this one exchanges.  (ProcessGroupNCCL runs the collective on its own
+            # stream and orders it against the calling stream itself.)  What does NOT work on this runtime - measured,
+            # profiles/r03_v3_exchange_experiments.txt: any per-step activity on an extra stream of this process (even a
+            # bare event record) or on the legacy default stream halves the concurrency of the 4 compute streams
+            # (0.37 -> 0.65-1.15 ms/step), and a hipStreamWaitEvent in front of a hipGraphLaunch does the same.
+            with torch.cuda.stream(lane['streams'][k]):
+                # (one set of receive buffers per stream in flight: a later step of ANOTHER stream never overwrites them)
+                qdist.gather_tokens(tokens if backend == 'nccl' else tokens.cpu(), 0, gathered[k] if gathered is not None else None)
         return tokens
 
     def timed(lane, steps, warmup, gathered=None):
@@ -526,7 +527,7 @@ def run(args):
         if use_dist and rank == 0 and gathered is not None:
             torch.cuda.synchronize()
             k_last = (steps - 1) % S
-            if not torch.equal(gathered[0].to(last[k_last].device), last[k_last]):
+            if not torch.equal(gathered[k_last][0].to(last[k_last].device), last[k_last]):
                 raise SystemExit('bench: tokens gathered from rank 0 differ from the local ones')
         return dt, t_enq, last[(steps - 1) % S]
 
@@ -538,7 +539,8 @@ def run(args):
     eng = lane['engs'][0]
     T_out = lane['T_out']
     log(f'{S} engine(s) ready ({len(blob) / 1e6:.1f} MB blob); warm-up')
-    gathered = [torch.empty(BATCH, T_out, dtype=torch.int32, device=comm_dev) for _ in range(world)] if rank == 0 else None
+    gathered = ([[torch.empty(BATCH, T_out, dtype=torch.int32, device=comm_dev) for _ in range(world)] for _ in range(S)]
+                if rank == 0 else None)
     dt, t_enq, tokens = timed(lane, args.steps, args.warmup, gathered)
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)

@@ -122,10 +122,15 @@ def test_committed_bench_lines_carry_the_contract_fields():
     import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import re
     files = sorted(glob.glob(os.path.join(root, 'profiles', 'r*_bench*.json')))
-    newest = os.path.basename(files[-1]).split('_bench')[0]
-    lines = [f for f in files if os.path.basename(f).startswith(newest) and 'under_rocprof' not in f]
-    assert lines
+
+    def tag(f):                                               # 'r03_v3_jasper_bench.json' -> (3, 3)
+        m = re.match(r'r(\d+)_v(\d+)_', os.path.basename(f))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    newest = max(tag(f) for f in files)
+    lines = [f for f in files if tag(f) == newest and 'under_rocprof' not in f]
+    assert len(lines) >= 2, lines                             # the headline configuration and at least one more
     for f in lines:
         r = json.loads(open(f).read().strip().splitlines()[-1])
         for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
@@ -137,6 +142,8 @@ def test_committed_bench_lines_carry_the_contract_fields():
         for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel'):
             assert k in ro, (f, k)
         assert ro['bound'] in ('hbm', 'mfma') and abs(ro['frac'] - ro['achieved'] / ro['peak']) < 1e-6
+        wgs = ro['other'].get('work_groups_per_launch')
+        assert wgs is None or 1 <= wgs <= 4096, (f, wgs)      # B x time tiles (x channel groups) of the dominant kernel
         cb = r['cpu_baseline']
         for k in ('value', 'unit', 'cores', 'kind', 'sample'):
             assert k in cb, (f, k)
