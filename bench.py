@@ -29,7 +29,8 @@ for p in (os.path.join(ROOT, 'q-asr_amd'), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# steps in flight live on separate HIP streams; ROCm maps streams onto 4 hardware queues by default
+# steps in flight live on separate HIP streams.  (Measured at the end of round 3: a PyTorch process on this image gets four
+# hardware queues with or without this variable - profiles/r03_v3_queue_experiments.txt - so 4 steps in flight is the cap.)
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 PEAK_INT8_OPS = 256 * 4 * 2048 * 2.4e9       # 256 CUs x 4 SIMDs x 1024 MAC/clk (v_mfma_i32_32x32x32_i8) x 2.4 GHz
@@ -441,7 +442,8 @@ def run(args):
         feature / length / token buffers (stable pointers: the forward replays as one hipGraph launch)."""
         engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance, tile=tile, graph=not args.no_graph,
                               persistent=bool(args.persistent)) for _ in range(S)]      # qasr_engine_opts (include/qasr.h)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        # (experiment QASR_BENCH_HIPRI=1: streams beyond the 4 normal-priority hardware queues come from the high-priority pool)
+        streams = [torch.cuda.Stream(device=dev, priority=(-1 if (j >= 4 and os.environ.get('QASR_BENCH_HIPRI')) else 0)) for j in range(S)]
         T_out = engs[0].out_frames(T_pad)
         audio = [torch.from_numpy(synth.make_audio(BATCH, SAMPLES, seed=100 + 16 * rank + k)).to(dev) for k in range(S)]
         bufs = [dict(fe=(torch.empty(BATCH, 64, T_pad, device=dev), torch.empty(BATCH, dtype=torch.int32, device=dev),
