@@ -214,6 +214,14 @@ def test_forward_audio_equals_frontend_plus_forward(golden_dir, fuse_norm, S):
             assert torch.equal(fbuf, feats), call
         assert torch.equal(lp, lp0) and torch.equal(tk, tk0) and torch.equal(el, el0), call
     assert e2.num_launches() == e1.num_launches() + (1 if fuse_norm else 2), (e1.num_launches(), e2.num_launches())
+    # a larger batch through the same engine: new plan, larger statistics buffer, the old graph must not be replayed
+    audio2, alen2 = torch.cat([audio, audio.flip(0)]).contiguous(), torch.cat([alen, alen.flip(0)]).contiguous()
+    for call in range(3):
+        with torch.cuda.stream(st):
+            lp2, tk2, el2 = e2.forward_audio(audio2, alen2, fb, win, plan, 0.97, 16)
+        torch.cuda.synchronize()
+        assert torch.equal(tk2[:B], tk0) and torch.equal(tk2[B:], tk0.flip(0)) and torch.equal(el2[:B], el0), call
+        assert torch.equal(lp2[:B], lp0), call
     e1.close()
     e2.close()
 
