@@ -567,6 +567,8 @@ def run(args):
                                'decoder + greedy argmax',
                    'global_batch': BATCH * world, 'seq_len': FRAMES, 'weights': 'random-init (qasr.synth, seed 0)',
                    'steps_in_flight': S, 'inputs': 'one audio batch per step in flight (different seeds)',
+                   'steps_in_flight_note': 'one 32-utterance launch chain per HIP stream; this process has 4 hardware queues '
+                                           '(profiles/r03_v3_queue_experiments.txt), so 4 is the cap',
                    'log_probs': 'not written in the timed step (tokens and encoded lengths are; the reference forward also returns '
                                 'log-probs: 0.9 MB of stores per step, want_logp=False here)',
                    'hip_graph': not args.no_graph,
