@@ -467,11 +467,10 @@ def run(args):
               # mel front-end + encoder + decoder as one engine call (one hipGraph launch per step)
               _, tokens, _ = lane['engs'][k].forward_audio(lane['audio'][k], alen, fb, window, fe_plan, 0.97, 16, want_logp=False,
                                                          feats=b['fe'][0], feat_lens=b['fe'][1], out=b['out'])
-            if step_trace is not None or os.environ.get('QASR_BENCH_DONE_EVENT'):   # (diagnostic only: an event record per step costs ~4 %)
+            if step_trace is not None:                            # (diagnostic only)
                 done = torch.cuda.Event(enable_timing=True)
                 done.record(lane['streams'][k])
-                if step_trace is not None:
-                    step_trace.append((i, k, done))
+                step_trace.append((i, k, done))
         if use_dist:
             # Exchange step: the step's tokens go to rank 0 through the one communicator, in step order, issued
             # ON THE STEP'S OWN COMPUTE STREAM: same-stream order puts the gather behind the step that produced the tokens
@@ -502,10 +501,7 @@ def run(args):
             dist.barrier()
         torch.cuda.synchronize()
         ev0 = torch.cuda.Event(enable_timing=True)
-        if os.environ.get('QASR_BENCH_EV0') == 'default':
-            ev0.record()                                         # (experiment: the legacy default stream)
-        else:
-            ev0.record(lane['streams'][0])                       # the region's device-side origin (diagnostic), on a stream of the lane
+        ev0.record(lane['streams'][0])                           # the region's device-side origin (diagnostic), on a stream of the lane
         t0 = time.perf_counter()
         last = {}
         if step_trace is not None:
