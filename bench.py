@@ -15,7 +15,8 @@ Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on 
 between one event pair) for the kernel instantiation with the largest share of the step; `cpu_baseline` times the
 reference's fake-quant CPU op sequence (oracle/fakequant_torch.py) on the host cores (N=1 only).
 `--config w6a6|jasper` runs BASELINE.json's configurations 3 / 4 through the same loop (config 2 is the default and the
-headline)."""
+headline).  At N = 1 the default run ALSO measures, after the headline region and never inside it, 20 steps each of config 3,
+config 4 and config 2 with log-probs written (`other_configs` in the JSON line; `--no-other-configs` skips them)."""
 import argparse
 import json
 import os
@@ -29,9 +30,9 @@ for p in (os.path.join(ROOT, 'q-asr_amd'), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# steps in flight live on separate HIP streams.  (Measured at the end of round 3: a PyTorch process on this image gets four
-# hardware queues with or without this variable - profiles/r03_v3_queue_experiments.txt - so 4 steps in flight is the cap.)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# Steps in flight live on separate HIP streams.  GPU_MAX_HW_QUEUES is NOT set here any more: with 4 streams it changes nothing,
+# and what more streams do is measured in profiles/r03_v3_queue_experiments.txt (8 streams do get 8 live queues with the
+# variable at 16 - and are slower: 0.525 ms/step; 4 launch chains is the measured optimum at batch 32).
 
 PEAK_INT8_OPS = 256 * 4 * 2048 * 2.4e9       # 256 CUs x 4 SIMDs x 1024 MAC/clk (v_mfma_i32_32x32x32_i8) x 2.4 GHz
 PEAK_HBM = 8.0e12
@@ -69,6 +70,14 @@ def parse_args(argv=None):
                     help='independent steps in flight per GPU (each on its own HIP stream + engine arena); 0 = the config default')
     ap.add_argument('--persistent', type=int, default=int(os.environ.get('QASR_BENCH_PERSISTENT', 0)),
                     help='1: runs of separable layers as one persistent launch (one work-group per utterance)')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the extra measurements of BASELINE.json configs 3 / 4 and of config 2 with log-probs (N = 1 only)')
+    ap.add_argument('--gather', choices=['tokens', 'logits'], default='tokens',
+                    help='what the per-step exchange sends to rank 0: int32 greedy tokens [B, T\'] (default; conv_asr.py:275 + '
+                         'ctc_models.py:405) or the float32 CTC log-probs [B, T\', 29] (north_star\'s wording; the step then writes them)')
+    ap.add_argument('--check-gather', action='store_true',
+                    help='after the timed region rank 0 recomputes every other rank\'s last steps locally (the audio seeds are a '
+                         'function of rank and stream) and compares them with what the gather delivered')
     ap.add_argument('--dry-run', action='store_true',
                     help='rank plumbing only (launcher, process group, blob broadcast, per-step token gather) on synthetic '
                          'payloads: no model, no engine, no GPU needed (gloo when no GPU is visible)')
@@ -154,6 +163,31 @@ def pmc_traffic():
                 if m:
                     out[m.group(1)] = out.get(m.group(1), 0.0) + mult * 1024.0 * float(m.group(4))
     return out, src
+
+
+def pmc_counters(kernel):
+    """rocprofv3's own matrix-pipe counters for `kernel`, from the newest committed summary profiles/r*_pmc_MFMA.json
+    (written by profiles/collect.sh from separate --pmc passes; not collected in this run): the fraction of the CUs' busy
+    cycles in which the MFMA pipe was busy, and int8 MFMA MOPS per launch."""
+    import glob
+    import re
+    def tag(path):
+        m = re.match(r'r(\d+)_v(\d+)', os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    fs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_MFMA.json')), key=tag)
+    if not fs:
+        return None
+    newest = tag(fs[-1])
+    for f in reversed([f for f in fs if tag(f) == newest]):
+        try:
+            rows = json.load(open(f)).get('kernels', {})
+        except (OSError, ValueError):
+            continue
+        row = rows.get(kernel) or rows.get(kernel.replace('qasr::', ''))
+        if row:
+            return {'mfma_busy_frac_rocprof': row.get('mfma_busy_frac'), 'rocprof_counters': row,
+                    'rocprof_counters_source': f'profiles/{os.path.basename(f)} (separate rocprofv3 --pmc passes of `bench.py --streams 1`, per-dispatch averages)'}
+    return None
 
 
 def host_cores():
@@ -279,24 +313,30 @@ def in_flight_timing(lane, roof, ops, reps=20):
     # the clock the chip holds meanwhile: every work-group of the kernel stamps its start / end (100 MHz s_memrealtime) and its
     # shader cycles (s_memtime) into a diagnostic buffer (qasr_debug_timeline; the timed launches above run without it)
     clock = None
+    import ctypes as C
+    import numpy as np
+    lib = lane['engs'][0].lib
+    buf = torch.zeros(4 * 16384, dtype=torch.int64, device='cuda')
     try:
-        import ctypes as C
-        import numpy as np
-        lib = lane['engs'][0].lib
-        buf = torch.zeros(4 * 16384, dtype=torch.int64, device='cuda')
         lib.qasr_debug_timeline(C.c_void_p(buf.data_ptr()), buf.numel() // 4)
         for _ in range(3):
             for o in ops:
                 for k in range(S):
                     lane['engs'][k].run_op(o, stream=lane['streams'][k])
         torch.cuda.synchronize()
-        lib.qasr_debug_timeline(C.c_void_p(0), 0)
         st = buf.cpu().numpy().reshape(-1, 4)
         st = st[(st[:, 1] > st[:, 0]) & (st[:, 3] > 0)]
         if len(st):
             clock = float(np.median(st[:, 3] / ((st[:, 1] - st[:, 0]) * 10.0)))      # cycles / ns = GHz
     except Exception as exc:                                     # diagnostics only
         log(f'clock probe skipped: {exc}')
+    finally:
+        # the process-global diagnostic pointer never outlives `buf`: launches still in flight are drained first, then the
+        # pointer is cleared on every path (a later graph capture would otherwise be refused, or stamps land in freed memory)
+        try:
+            torch.cuda.synchronize()
+        finally:
+            lib.qasr_debug_timeline(C.c_void_p(0), 0)
     extra = {}
     if clock:
         peak_at_clock = PEAK_INT8_OPS * clock / 2.4
@@ -373,6 +413,209 @@ def run_dry(args, rank, world):
                           'backend': 'nccl' if use_gpu else 'gloo'}))
 
 
+class Workload:
+    """One BASELINE.json configuration on this rank: the calibrated + packed model (rank 0 builds it, the others receive the
+    blob over the process group), the front-end plan, and the step / timed-region loop over S steps in flight."""
+
+    def __init__(self, args, config, env):
+        import torch
+        from qasr import dist as qdist
+        from qasr import engine, topology
+        self.args, self.env, self.config = args, env, config
+        self.model_name, self.wbit, self.abit, self.batch, self.S_default, self.baseline_cfg = CONFIGS[config]
+        self.batch_override = 'QASR_BENCH_BATCH' in os.environ
+        if self.batch_override:                                  # (experiment: several batches per launch; the metric label follows it)
+            self.batch = int(os.environ['QASR_BENCH_BATCH'])
+        rank, dev, comm_dev = env['rank'], env['dev'], env['comm_dev']
+        self.lib = engine.load_library()
+        self.cfg = topology.MODELS[self.model_name]()
+        # rank 0 calibrates + packs; the packed int weights travel to the other ranks over RCCL/xGMI
+        self.blob = self.meta = self.amin = self.amax = None
+        fb, window = torch.zeros(64, 257), torch.zeros(320)
+        if rank == 0:
+            self.blob, self.meta, fb, window, self.amin, self.amax = build_model(dev, self.model_name, self.wbit, self.abit)
+        self.n_ranks_seen, self.blob_digests_equal = 1, None
+        if env['use_dist']:
+            import hashlib
+            dist = env['dist']
+            self.blob = qdist.broadcast_blob(self.blob, 0, comm_dev)     # receiving ranks validate it (qasr_blob_check)
+            fb, window = qdist.broadcast_tensors([fb, window], 0, comm_dev)
+            ones = torch.ones(1, dtype=torch.int64, device=comm_dev)
+            dist.all_reduce(ones)
+            self.n_ranks_seen = int(ones[0])
+            # every rank's engines are built from the bytes IT holds: compare their digests with rank 0's
+            dig = torch.frombuffer(bytearray(hashlib.sha256(self.blob).digest()), dtype=torch.uint8).to(torch.int64).to(comm_dev)
+            lo, hi = dig.clone(), dig.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            self.blob_digests_equal = bool(torch.equal(lo, hi))
+        self.fb, self.window = fb.to(dev), window.to(dev)
+        self.T_pad = self.lib.qasr_frontend_frames(SAMPLES, 16)
+        self.lib_ws = self.lib.qasr_frontend_workspace_bytes(self.batch, SAMPLES, 64)
+        self.fe_plan = engine.frontend_plan(self.fb)  # filterbank-only tables, built once like a model does (ctc_models._frontend_hip)
+        self.alen = torch.full((self.batch,), SAMPLES, dtype=torch.int32, device=dev)
+        self.step_trace = [] if os.environ.get('QASR_BENCH_STEP_TRACE') else None   # (diagnostic) when each step finished
+
+    def audio_seed(self, rank, k):
+        return 100 + 16 * rank + k
+
+    def make_lane(self, S, tile, want_logp=False, rank=None):
+        """S steps in flight: per step in flight an engine (own arena), a HIP stream, its own audio batch and its own
+        feature / length / token (/ log-prob) buffers (stable pointers: the forward replays as one hipGraph launch)."""
+        import torch
+        from qasr import engine, synth
+        args, dev, B = self.args, self.env['dev'], self.batch
+        rank = self.env['rank'] if rank is None else rank
+        engs = [engine.Engine(self.blob, self.env['local'], whole_utterance=args.whole_utterance, tile=tile, graph=not args.no_graph,
+                              persistent=bool(args.persistent)) for _ in range(S)]      # qasr_engine_opts (include/qasr.h)
+        # (experiment QASR_BENCH_HIPRI=1: streams beyond the 4 normal-priority hardware queues come from the high-priority pool)
+        streams = [torch.cuda.Stream(device=dev, priority=(-1 if (j >= 4 and os.environ.get('QASR_BENCH_HIPRI')) else 0)) for j in range(S)]
+        T_out = engs[0].out_frames(self.T_pad)
+        audio = [torch.from_numpy(synth.make_audio(B, SAMPLES, seed=self.audio_seed(rank, k))).to(dev) for k in range(S)]
+        ncls = engs[0].n_classes
+        bufs = [dict(fe=(torch.empty(B, 64, self.T_pad, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+                         torch.empty(max(self.lib_ws, 16), dtype=torch.uint8, device=dev)),
+                     out=(torch.empty(B, T_out, ncls, device=dev) if want_logp else None,
+                          torch.empty(B, T_out, dtype=torch.int32, device=dev),
+                          torch.empty(B, dtype=torch.int32, device=dev))) for _ in range(S)]
+        return dict(S=S, engs=engs, streams=streams, audio=audio, bufs=bufs, T_out=T_out, want_logp=want_logp, n_classes=ncls)
+
+    def step(self, lane, i, gathered=None):
+        import torch
+        from qasr import dist as qdist
+        from qasr import engine
+        k = i % lane['S']
+        b = lane['bufs'][k]
+        want_logp = lane['want_logp']
+        with torch.cuda.stream(lane['streams'][k]):
+            if os.environ.get('QASR_BENCH_SPLIT_FE'):            # (A/B) front-end as its own two launches in front of the graph
+                feats, flen = engine.frontend_mel(lane['audio'][k], self.alen, self.fb, self.window, 0.97, 16, out=b['fe'], plan=self.fe_plan)
+                logp, tokens, _ = lane['engs'][k].forward(feats, flen, want_logp=want_logp, out=b['out'])
+            else:
+                # mel front-end + encoder + decoder as one engine call (one hipGraph launch per step)
+                logp, tokens, _ = lane['engs'][k].forward_audio(lane['audio'][k], self.alen, self.fb, self.window, self.fe_plan, 0.97, 16,
+                                                                want_logp=want_logp, feats=b['fe'][0], feat_lens=b['fe'][1], out=b['out'])
+            if self.step_trace is not None:                       # (diagnostic only)
+                done = torch.cuda.Event(enable_timing=True)
+                done.record(lane['streams'][k])
+                self.step_trace.append((i, k, done))
+        if self.env['use_dist'] and gathered is not False:
+            # Exchange step (SURVEY 8e): the step's result goes to rank 0 through the one communicator, in step order, issued
+            # ON THE STEP'S OWN COMPUTE STREAM: same-stream order puts the gather behind the step that produced the tokens
+            # and in front of the step that overwrites them (4 steps later), so no event of this file's making is needed;
+            # the other 3 streams keep computing while this one exchanges.  (ProcessGroupNCCL runs the collective on its own
+            # stream and orders it against the calling stream itself.)  What does NOT work on this runtime - measured,
+            # profiles/r03_v3_exchange_experiments.txt: any per-step activity on an extra stream of this process (even a
+            # bare event record) or on the legacy default stream halves the concurrency of the 4 compute streams
+            # (0.37 -> 0.65-1.15 ms/step), and a hipStreamWaitEvent in front of a hipGraphLaunch does the same.
+            payload = logp if self.args.gather == 'logits' else tokens
+            with torch.cuda.stream(lane['streams'][k]):
+                # (one set of receive buffers per stream in flight: a later step of ANOTHER stream never overwrites them)
+                qdist.gather_tokens(payload if self.env['backend'] == 'nccl' else payload.cpu(), 0,
+                                    gathered[k] if gathered is not None else None)
+        return tokens
+
+    def timed(self, lane, steps, warmup, gathered=None):
+        """One-time setup like the model build (each engine's first forward launches kernel by kernel, the second is captured
+        into its hipGraph; the serial results of that phase are the reference every later step must reproduce), `warmup`
+        untimed steps, then EXACTLY `steps` steps between barrier + synchronize pairs."""
+        import torch
+        env, step_trace = self.env, self.step_trace
+        dist = env['dist'] if (env['use_dist'] and gathered is not False) else None
+        S = lane['S']
+        ref = []
+        for i in range(2 * S):
+            t_ = self.step(lane, i, gathered)
+            torch.cuda.synchronize()
+            if i >= S:
+                ref.append(t_.clone())
+        for i in range(warmup):
+            self.step(lane, i, gathered)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record(lane['streams'][0])                           # the region's device-side origin (diagnostic), on a stream of the lane
+        t0 = time.perf_counter()
+        last = {}
+        if step_trace is not None:
+            step_trace.clear()
+        for i in range(steps):
+            last[i % S] = self.step(lane, i, gathered)
+        t_enq = time.perf_counter() - t0
+        ends = []
+        for st in lane['streams']:                               # when each stream's last step finished (diagnostic)
+            e_ = torch.cuda.Event(enable_timing=True)
+            e_.record(st)
+            ends.append(e_)
+        torch.cuda.synchronize()
+        log('streams finished at ' + ', '.join(f'{ev0.elapsed_time(e_):.2f}' for e_ in ends) + ' ms after the region began')
+        if step_trace is not None:
+            for k in range(S):
+                log(f'  stream {k}: steps finished at ' + ' '.join(f'{ev0.elapsed_time(e_):.2f}' for i_, k_, e_ in step_trace if k_ == k))
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        # every step in flight decodes its own batch: each must reproduce its serial result bit for bit
+        for k, t_ in last.items():
+            if not torch.equal(t_, ref[k]):
+                raise SystemExit(f'bench: stream {k} produced different tokens with other steps in flight')
+        if dist is not None and env['rank'] == 0 and gathered is not None:
+            torch.cuda.synchronize()
+            for k in last:                                       # rank 0's own slot of every stream's receive buffers
+                mine = lane['bufs'][k]['out'][0] if self.args.gather == 'logits' else last[k]
+                if not torch.equal(gathered[k][0].to(mine.device), mine):
+                    raise SystemExit(f'bench: what the gather delivered for rank 0 (stream {k}) differs from the local result')
+        return dt, t_enq, last[(steps - 1) % S]
+
+    def check_gather(self, lane, gathered, steps):
+        """Rank 0 recomputes the other ranks' steps itself - their audio is a function of (rank, stream) - with a serial
+        one-step-in-flight engine and compares with what the last gather of every stream delivered.  Returns the ranks checked."""
+        import torch
+        S = lane['S']
+        checked = []
+        for r in range(1, self.env['world']):
+            lane_r = self.make_lane(S, 32, want_logp=self.args.gather == 'logits', rank=r)
+            for k in range(min(S, steps)):
+                tok = self.step(lane_r, k, gathered=False)
+                torch.cuda.synchronize()
+                want = lane_r['bufs'][k]['out'][0] if self.args.gather == 'logits' else tok
+                if not torch.equal(gathered[k][r].to(want.device), want):
+                    raise SystemExit(f'bench: rank {r}, stream {k}: gathered result differs from a local recomputation')
+            for e_ in lane_r['engs']:
+                e_.close()
+            checked.append(r)
+        return checked
+
+
+def measure_other_config(args, env, name, steps, warmup, want_logp=False, base=None):
+    """20 steps of another BASELINE.json configuration through the same loop (own model, own engines), AFTER the headline
+    region: {ms_per_step, rtfx, step_mfma_frac, roofline of its dominant kernel}.  `base`: reuse the headline workload
+    (config 2 with log-probs written)."""
+    import numpy as np
+    import torch
+    w = base or Workload(args, name, env)
+    S = max(1, args.streams or w.S_default)
+    lane = w.make_lane(S, args.tile or (128 if S > 1 else 32), want_logp=want_logp)
+    dt, _, _ = w.timed(lane, steps, warmup, gathered=False)
+    per = dt / steps
+    mfma_ops, _, step_bytes = algorithmic_work(w.cfg, w.batch, FRAMES // 2)
+    out = {'baseline_config': w.baseline_cfg, 'workload': f'{w.model_name} w{w.wbit}a{w.abit} bs{w.batch}' + (' + log-probs written' if want_logp else ''),
+           'steps': steps, 'warmup': warmup, 'steps_in_flight': S, 'ms_per_step': 1e3 * per,
+           'rtfx': w.batch * SAMPLES / 16000.0 / per, 'step_mfma_frac': mfma_ops / per / PEAK_INT8_OPS,
+           'step_hbm_frac': step_bytes / per / PEAK_HBM}
+    if base is None:
+        torch.cuda.synchronize()
+        roof = dominant_kernel_roofline(lane['engs'][0], w.cfg, w.meta, lane['engs'][0].time_ops(reps=20).astype(np.float64), w.batch, FRAMES // 2)
+        out['blob_mb'] = len(w.blob) / 1e6
+        out['roofline'] = {k: roof[k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us', 'launches_per_step',
+                                                 'share_of_step_device_time', 'traffic')}
+    for e_ in lane['engs']:
+        e_.close()
+    log(f'other config {name}{" + logp" if want_logp else ""}: {1e3 * per:.3f} ms/step')
+    return out
+
+
 def run(args):
     import numpy as np
     import torch
@@ -393,8 +636,6 @@ def run(args):
         return run_dry(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the integer engine has no CPU fallback')
-    model_name, wbit, abit, BATCH, S_default, baseline_cfg = CONFIGS[args.config]
-    BATCH = int(os.environ.get('QASR_BENCH_BATCH', BATCH))          # (experiments: several batches per launch)
     # QASR_BENCH_BACKEND=gloo rehearses the N>1 control flow on a one-GPU box: every rank uses GPU 0 and the two
     # exchange steps go through host memory.  The measured configuration is always nccl (= RCCL), one GPU per rank.
     backend = os.environ.get('QASR_BENCH_BACKEND', 'nccl')
@@ -413,167 +654,62 @@ def run(args):
             dist.init_process_group('nccl', device_id=dev)     # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend)
+    env = dict(rank=rank, local=local, world=world, dev=dev, comm_dev=comm_dev, dist=dist, backend=backend, use_dist=use_dist)
 
     from qasr import engine, synth, topology
-    from qasr import dist as qdist
-    lib = engine.load_library()
-    cfg = topology.MODELS[model_name]()
-
-    # rank 0 calibrates + packs; the packed int weights travel to the other ranks over RCCL/xGMI
-    blob = meta = None
-    fb, window = torch.zeros(64, 257), torch.zeros(320)
-    if rank == 0:
-        blob, meta, fb, window, amin, amax = build_model(dev, model_name, wbit, abit)
-    n_ranks_seen = 1
-    if use_dist:
-        blob = qdist.broadcast_bytes(blob, 0, comm_dev)
-        fb, window = qdist.broadcast_tensors([fb, window], 0, comm_dev)
-        ones = torch.ones(1, dtype=torch.int64, device=comm_dev)
-        dist.all_reduce(ones)
-        n_ranks_seen = int(ones[0])
-    fb, window = fb.to(dev), window.to(dev)
-
-    T_pad = lib.qasr_frontend_frames(SAMPLES, 16)
-    lib_ws = lib.qasr_frontend_workspace_bytes(BATCH, SAMPLES, 64)
-    fe_plan = engine.frontend_plan(fb)     # filterbank-only tables, built once like a model does (ctc_models._frontend_hip)
-
-    def make_lane(S, tile):
-        """S steps in flight: per step in flight an engine (own arena), a HIP stream, its own audio batch and its own
-        feature / length / token buffers (stable pointers: the forward replays as one hipGraph launch)."""
-        engs = [engine.Engine(blob, local, whole_utterance=args.whole_utterance, tile=tile, graph=not args.no_graph,
-                              persistent=bool(args.persistent)) for _ in range(S)]      # qasr_engine_opts (include/qasr.h)
-        # (experiment QASR_BENCH_HIPRI=1: streams beyond the 4 normal-priority hardware queues come from the high-priority pool)
-        streams = [torch.cuda.Stream(device=dev, priority=(-1 if (j >= 4 and os.environ.get('QASR_BENCH_HIPRI')) else 0)) for j in range(S)]
-        T_out = engs[0].out_frames(T_pad)
-        audio = [torch.from_numpy(synth.make_audio(BATCH, SAMPLES, seed=100 + 16 * rank + k)).to(dev) for k in range(S)]
-        bufs = [dict(fe=(torch.empty(BATCH, 64, T_pad, device=dev), torch.empty(BATCH, dtype=torch.int32, device=dev),
-                         torch.empty(max(lib_ws, 16), dtype=torch.uint8, device=dev)),
-                     out=(None, torch.empty(BATCH, T_out, dtype=torch.int32, device=dev),
-                          torch.empty(BATCH, dtype=torch.int32, device=dev))) for _ in range(S)]
-        return dict(S=S, engs=engs, streams=streams, audio=audio, bufs=bufs, T_out=T_out)
-
-    alen = torch.full((BATCH,), SAMPLES, dtype=torch.int32, device=dev)
-
-    step_trace = [] if os.environ.get('QASR_BENCH_STEP_TRACE') else None   # (diagnostic) when each step finished
-
-    def step(lane, i, gathered=None):
-        k = i % lane['S']
-        b = lane['bufs'][k]
-        with torch.cuda.stream(lane['streams'][k]):
-            if os.environ.get('QASR_BENCH_SPLIT_FE'):            # (A/B) front-end as its own two launches in front of the graph
-                feats, flen = engine.frontend_mel(lane['audio'][k], alen, fb, window, 0.97, 16, out=b['fe'], plan=fe_plan)
-                _, tokens, _ = lane['engs'][k].forward(feats, flen, want_logp=False, out=b['out'])
-            else:
-              # mel front-end + encoder + decoder as one engine call (one hipGraph launch per step)
-              _, tokens, _ = lane['engs'][k].forward_audio(lane['audio'][k], alen, fb, window, fe_plan, 0.97, 16, want_logp=False,
-                                                         feats=b['fe'][0], feat_lens=b['fe'][1], out=b['out'])
-            if step_trace is not None:                            # (diagnostic only)
-                done = torch.cuda.Event(enable_timing=True)
-                done.record(lane['streams'][k])
-                step_trace.append((i, k, done))
-        if use_dist:
-            # Exchange step (SURVEY 8e): the step's tokens go to rank 0 through the one communicator, in step order, issued
-            # ON THE STEP'S OWN COMPUTE STREAM: same-stream order puts the gather behind the step that produced the tokens
-            # and in front of the step that overwrites them (4 steps later), so no event of this file's making is needed;
-            # the other 3 streams keep computing while this one exchanges.  (ProcessGroupNCCL runs the collective on its own
-            # stream and orders it against the calling stream itself.)  What does NOT work on this runtime - measured,
-            # profiles/r03_v3_exchange_experiments.txt: any per-step activity on an extra stream of this process (even a
-            # bare event record) or on the legacy default stream halves the concurrency of the 4 compute streams
-            # (0.37 -> 0.65-1.15 ms/step), and a hipStreamWaitEvent in front of a hipGraphLaunch does the same.
-            with torch.cuda.stream(lane['streams'][k]):
-                # (one set of receive buffers per stream in flight: a later step of ANOTHER stream never overwrites them)
-                qdist.gather_tokens(tokens if backend == 'nccl' else tokens.cpu(), 0, gathered[k] if gathered is not None else None)
-        return tokens
-
-    def timed(lane, steps, warmup, gathered=None):
-        # one-time setup, like the model build: each engine's first forward launches kernel by kernel, the second is
-        # captured into its hipGraph; the serial results of that phase are the reference every later step must reproduce
-        S = lane['S']
-        ref = []
-        for i in range(2 * S):
-            t_ = step(lane, i, gathered)
-            torch.cuda.synchronize()
-            if i >= S:
-                ref.append(t_.clone())
-        for i in range(warmup):
-            step(lane, i, gathered)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev0.record(lane['streams'][0])                           # the region's device-side origin (diagnostic), on a stream of the lane
-        t0 = time.perf_counter()
-        last = {}
-        if step_trace is not None:
-            step_trace.clear()
-        for i in range(steps):
-            last[i % S] = step(lane, i, gathered)
-        t_enq = time.perf_counter() - t0
-        ends = []
-        for st in lane['streams']:                               # when each stream's last step finished (diagnostic)
-            e_ = torch.cuda.Event(enable_timing=True)
-            e_.record(st)
-            ends.append(e_)
-        torch.cuda.synchronize()
-        log('streams finished at ' + ', '.join(f'{ev0.elapsed_time(e_):.2f}' for e_ in ends) + ' ms after the region began')
-        if step_trace is not None:
-            for k in range(S):
-                log(f'  stream {k}: steps finished at ' + ' '.join(f'{ev0.elapsed_time(e_):.2f}' for i_, k_, e_ in step_trace if k_ == k))
-        if use_dist:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        # every step in flight decodes its own batch: each must reproduce its serial result bit for bit
-        for k, t_ in last.items():
-            if not torch.equal(t_, ref[k]):
-                raise SystemExit(f'bench: stream {k} produced different tokens with other steps in flight')
-        if use_dist and rank == 0 and gathered is not None:
-            torch.cuda.synchronize()
-            k_last = (steps - 1) % S
-            if not torch.equal(gathered[k_last][0].to(last[k_last].device), last[k_last]):
-                raise SystemExit('bench: tokens gathered from rank 0 differ from the local ones')
-        return dt, t_enq, last[(steps - 1) % S]
+    w = Workload(args, args.config, env)
+    model_name, wbit, abit, BATCH, baseline_cfg, cfg = w.model_name, w.wbit, w.abit, w.batch, w.baseline_cfg, w.cfg
 
     # throughput mode: consecutive steps are independent batches, so S of them are kept in flight, each on its own
     # HIP stream with its own engine arena (kernels of different steps overlap each other's launch gaps and tails)
-    S = max(1, args.streams or S_default)
+    S = max(1, args.streams or w.S_default)
     tile = args.tile or (128 if S > 1 else 32)
-    lane = make_lane(S, tile)
+    lane = w.make_lane(S, tile, want_logp=args.gather == 'logits')
     eng = lane['engs'][0]
     T_out = lane['T_out']
-    log(f'{S} engine(s) ready ({len(blob) / 1e6:.1f} MB blob); warm-up')
-    gathered = ([[torch.empty(BATCH, T_out, dtype=torch.int32, device=comm_dev) for _ in range(world)] for _ in range(S)]
+    log(f'{S} engine(s) ready ({len(w.blob) / 1e6:.1f} MB blob); warm-up')
+    gshape, gdtype = ((BATCH, T_out, lane['n_classes']), torch.float32) if args.gather == 'logits' else ((BATCH, T_out), torch.int32)
+    gathered = ([[torch.empty(gshape, dtype=gdtype, device=comm_dev) for _ in range(world)] for _ in range(S)]
                 if rank == 0 else None)
-    dt, t_enq, tokens = timed(lane, args.steps, args.warmup, gathered)
+    dt, t_enq, tokens = w.timed(lane, args.steps, args.warmup, gathered)
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
     audio_s = world * BATCH * SAMPLES / 16000.0 * args.steps
     log(f'timed {args.steps} steps: {1e3 * dt / args.steps:.3f} ms/step (host enqueue {1e3 * t_enq / args.steps:.3f} ms/step)')
-    metric = ('RTFx (audio-sec/wall-sec) QuartzNet15x5 int8 bs32' if args.config == 'quartznet'
+    metric = ('RTFx (audio-sec/wall-sec) QuartzNet15x5 int8 bs32' if (args.config == 'quartznet' and not w.batch_override)
               else f'RTFx (audio-sec/wall-sec) {model_name} w{wbit}a{abit} bs{BATCH}')
     result = {
         'metric': metric, 'value': audio_s / dt, 'unit': 'audio-s/wall-s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': f'int{wbit} (s8 x s8 -> i32 on MFMA; float64 fixed-point requant)',
-        'data': 'synthetic', 'n_ranks_seen': n_ranks_seen,
+        'data': 'synthetic', 'n_ranks_seen': w.n_ranks_seen,
         'config': {'workload': f'BASELINE.json config {baseline_cfg}: {model_name} w{wbit}a{abit} percentile=99.996, bs={BATCH}/GPU, '
                                '5 s synthetic 16 kHz audio (500 mel frames): HIP mel front-end + integer encoder + CTC '
-                               'decoder + greedy argmax',
+                               'decoder + greedy argmax' + (' [QASR_BENCH_BATCH override: NOT the BASELINE batch]' if w.batch_override else ''),
                    'global_batch': BATCH * world, 'seq_len': FRAMES, 'weights': 'random-init (qasr.synth, seed 0)',
                    'steps_in_flight': S, 'inputs': 'one audio batch per step in flight (different seeds)',
-                   'steps_in_flight_note': 'one 32-utterance launch chain per HIP stream; this process has 4 hardware queues '
-                                           '(profiles/r03_v3_queue_experiments.txt), so 4 is the cap',
-                   'log_probs': 'not written in the timed step (tokens and encoded lengths are; the reference forward also returns '
-                                'log-probs: 0.9 MB of stores per step, want_logp=False here)',
+                   'steps_in_flight_note': f'one {BATCH}-utterance launch chain per HIP stream; 4 chains is the measured optimum at batch 32 '
+                                           '(profiles/r03_v3_queue_experiments.txt: 8 live queues are slower)',
+                   'log_probs': ('written in the timed step (the exchange gathers them)' if args.gather == 'logits' else
+                                 'not written in the timed step (tokens and encoded lengths are; the reference forward also returns '
+                                 'log-probs: 0.9 MB of stores per step - other_configs.quartznet_with_logp times that variant)'),
                    'hip_graph': not args.no_graph,
                    'kernels': ('k_utt' if args.whole_utterance else
                                'k_dense2 (128 output channels x 256 / 128 frames per work-group), k_dense, k_sep' if args.config == 'jasper' else
                                f'k_mel, k_stem (normalisation + block 0), k_sep2 ({tile}-frame tiles; block 16: its dilation-2 form), k_dec') + (', persistent launch' if args.persistent else ''),
-                   'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + token gather' if use_dist else ''),
+                   'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + {"token" if args.gather == "tokens" else "logits"} gather' if use_dist else ''),
                    'wer': 'not measurable here: no LibriSpeech / checkpoint in the image'},
     }
+    if use_dist:
+        result['blob_digests_equal_across_ranks'] = w.blob_digests_equal
+        if args.check_gather:
+            checked = w.check_gather(lane, gathered, args.steps) if rank == 0 else None
+            dist.barrier()
+            if rank == 0:
+                result['gather_checked_ranks'] = checked
 
     if rank == 0:
         # ---- roofline of the dominant kernel, HIP events on the launch stream ---------------------------------
@@ -581,7 +717,7 @@ def run(args):
         # (qasr_engine_time_ops); buffers hold the real activations of the last timed step
         torch.cuda.synchronize()
         ms = eng.time_ops(reps=20).astype(np.float64)
-        result['roofline'] = dominant_kernel_roofline(eng, cfg, meta, ms, BATCH, FRAMES // 2)
+        result['roofline'] = dominant_kernel_roofline(eng, cfg, w.meta, ms, BATCH, FRAMES // 2)
         dom_ops = result['roofline'].pop('_ops')
         if S > 1:
             result['roofline']['other']['in_flight'] = in_flight_timing(lane, result['roofline'], dom_ops)
@@ -594,21 +730,24 @@ def run(args):
                                            step_algorithmic_gb_s=step_bytes / (dt / args.steps) / 1e9,
                                            step_hbm_frac=step_bytes / (dt / args.steps) / PEAK_HBM,
                                            work_groups_per_launch=result['roofline'].pop('_wgs', None))
+        counters = pmc_counters(result['roofline']['kernel'])
+        if counters:
+            result['roofline']['other'].update(counters)
     for e_ in lane['engs']:
         e_.close()
 
     if world == 1 and rank == 0:
         # ---- one step in flight (32-frame tiles): the latency view of the same workload ------------------------
         if S > 1 and not args.whole_utterance:
-            lane1 = make_lane(1, 32)
-            dt1, _, _ = timed(lane1, args.steps, args.warmup)
+            lane1 = w.make_lane(1, 32)
+            dt1, _, _ = w.timed(lane1, args.steps, args.warmup, gathered=False)
             result['single_stream_ms_per_step'] = 1e3 * dt1 / args.steps
             result['single_stream_rtfx'] = BATCH * SAMPLES / 16000.0 * args.steps / dt1
             log(f'one step in flight, 32-frame tiles: {1e3 * dt1 / args.steps:.3f} ms/step')
             # the same layer at the launch geometry of that mode: 256 work-groups, ONE launch fills the chip - the
             # figure `roofline.frac` (a 64-work-group launch alone on a 256-CU chip) cannot show
             torch.cuda.synchronize()
-            r1 = dominant_kernel_roofline(lane1['engs'][0], cfg, meta, lane1['engs'][0].time_ops(reps=20).astype(np.float64),
+            r1 = dominant_kernel_roofline(lane1['engs'][0], cfg, w.meta, lane1['engs'][0].time_ops(reps=20).astype(np.float64),
                                           BATCH, FRAMES // 2)
             result['roofline']['other']['one_launch_fills_chip'] = {
                 'kernel': r1['kernel'], 'work_groups_per_launch': r1['_wgs'], 'avg_launch_us': r1['avg_launch_us'],
@@ -618,6 +757,12 @@ def run(args):
                           'nothing else in flight'}
             for e_ in lane1['engs']:
                 e_.close()
+        # ---- BASELINE.json configs 3 / 4 and config 2 with log-probs, after the headline region (driver-visible) -
+        if args.config == 'quartznet' and not args.no_other_configs and not use_dist and not w.batch_override:
+            oc = {'quartznet_with_logp': measure_other_config(args, env, 'quartznet', 20, 5, want_logp=True, base=w)}
+            for name in ('w6a6', 'jasper'):
+                oc[name] = measure_other_config(args, env, name, 20, 5)
+            result['other_configs'] = oc
         # ---- CPU baseline: the reference's fake-quant op sequence on this host's cores (N=1 only) --------------
         if not args.no_cpu_baseline:
             from oracle.fakequant_torch import FakeQuantNet
@@ -625,9 +770,9 @@ def run(args):
             torch.set_num_threads(cores)
             log(f'roofline pass done; CPU baseline on {cores} host threads')
             sd = synth.make_state_dict(cfg, 0)
-            net = FakeQuantNet(topology.conv_plan(cfg), cfg, sd, amin, amax, wbit, abit)
-            audio0 = torch.from_numpy(synth.make_audio(BATCH, SAMPLES, seed=100 + 16 * rank + (args.steps - 1) % S)).to(dev)
-            feats, _ = engine.frontend_mel(audio0, alen, fb, window, 0.97, 16)
+            net = FakeQuantNet(topology.conv_plan(cfg), cfg, sd, w.amin, w.amax, wbit, abit)
+            audio0 = torch.from_numpy(synth.make_audio(BATCH, SAMPLES, seed=w.audio_seed(rank, (args.steps - 1) % S))).to(dev)
+            feats, _ = engine.frontend_mel(audio0, w.alen, w.fb, w.window, 0.97, 16)
             Bs = BATCH                                           # the same 32 x 500-frame batch the GPU timed
             x = feats[:Bs, :, :FRAMES].cpu().numpy()
             lens = [FRAMES] * Bs

@@ -130,6 +130,13 @@ typedef struct qasr_op_desc {
   qasr_pane panes[QASR_MAX_PANES];
 } qasr_op_desc;
 
+/* Host-only validation of a packed model (no GPU is touched): QASR_OK, or QASR_ERR_BLOB with a message in `err` (may be
+ * NULL) when the header, a table entry or any data offset + extent an op refers to falls outside the blob, an index is
+ * out of range, an op's output mode does not match its tensor's element size, or operand time domains disagree.  The
+ * reference's loader is unchecked (nemo/core/classes/modelPT.py:379-400); here a blob may have travelled over RCCL
+ * (qasr/dist.py) and every field ends up in a kernel argument.  qasr_engine_create[_ex] runs it first. */
+int qasr_blob_check(const void* blob, size_t blob_bytes, char* err, size_t err_cap);
+
 /* ---- engine -------------------------------------------------------------------------------- */
 typedef struct qasr_engine qasr_engine;
 

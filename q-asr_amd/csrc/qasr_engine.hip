@@ -406,16 +406,12 @@ int qasr_engine_create_ex(const void* blob, size_t n, int device, const qasr_eng
     return fail(QASR_ERR_ARG, "qasr_engine_opts.tile_frames %d (0, 32, 64 or 128)", o.tile_frames);
   if (o.sep_gen < 0 || o.sep_gen > 2) return fail(QASR_ERR_ARG, "qasr_engine_opts.sep_gen %d (0, 1 or 2)", o.sep_gen);
   const int debug = (int)o.debug;
+  {                                                          // every offset / index / shape of the blob, before any HIP call
+    char why[256];
+    if (qasr_blob_check(blob, n, why, sizeof why) != QASR_OK) return fail(QASR_ERR_BLOB, "%s", why);
+  }
   qasr_blob_header h;
   memcpy(&h, blob, sizeof h);
-  if (h.magic != QASR_BLOB_MAGIC || h.version != QASR_BLOB_VERSION) return fail(QASR_ERR_BLOB, "bad magic / version");
-  if (h.total_bytes != n || h.reserved != sizeof(qasr_op_desc))
-    return fail(QASR_ERR_BLOB, "size mismatch: blob %zu vs header %llu, op record %u vs %zu", n,
-                (unsigned long long)h.total_bytes, h.reserved, sizeof(qasr_op_desc));
-  if (h.tensors_off + (uint64_t)h.n_tensors * sizeof(qasr_tensor_desc) > n ||
-      h.ops_off + (uint64_t)h.n_ops * sizeof(qasr_op_desc) > n ||
-      h.domains_off + (uint64_t)h.n_domains * sizeof(qasr_domain_desc) > n || h.data_off > n)
-    return fail(QASR_ERR_BLOB, "table offsets out of range");
   HIPCHK(hipSetDevice(device));
   qasr_engine* e = new qasr_engine();
   e->device = device;
@@ -453,13 +449,6 @@ int qasr_engine_create_ex(const void* blob, size_t n, int device, const qasr_eng
   e->tdesc = (const qasr_tensor_desc*)(e->blob.data() + h.tensors_off);
   e->ops = (const qasr_op_desc*)(e->blob.data() + h.ops_off);
   e->doms = (const qasr_domain_desc*)(e->blob.data() + h.domains_off);
-  for (uint32_t i = 0; i < h.n_ops; ++i) {
-    const qasr_op_desc& op = e->ops[i];
-    if (op.kind > QASR_OP_REQUANT || op.n_panes > QASR_MAX_PANES || op.in < 0 || op.in >= (int)h.n_tensors) {
-      delete e;
-      return fail(QASR_ERR_BLOB, "op %u malformed", i);
-    }
-  }
   if (hipMalloc((void**)&e->dblob, n + 256) != hipSuccess ||      // slack: 16-byte granule copies may overrun an array's tail
       hipMemcpy(e->dblob, blob, n, hipMemcpyHostToDevice) != hipSuccess) {
     delete e;

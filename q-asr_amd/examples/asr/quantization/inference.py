@@ -51,6 +51,8 @@ def main():
     p.add_argument("--calib_early_stop", type=int, default=None)
     p.add_argument("--synthetic_calib", type=int, default=0, help="(extension) generate N seeded calibration batches")
     p.add_argument("--synthetic_model", action='store_true', help="(extension) random-init weights of --asr_model")
+    p.add_argument("--dither", type=float, default=None, help="(extension) override the preprocessor's dither (0: reproducible runs)")
+    p.add_argument("--dump_hyps", type=str, default=None, help="(extension) write hypotheses, references and WER as JSON")
     args = p.parse_args()
     torch.set_grad_enabled(False)
 
@@ -61,6 +63,8 @@ def main():
     else:
         asr_model = EncDecCTCModel.from_pretrained(model_name=args.asr_model)
     asr_model = asr_model.cuda()
+    if args.dither is not None:
+        asr_model.preprocessor.featurizer.dither = args.dither
     asr_model.setup_test_data(test_data_config={
         'sample_rate': 16000, 'manifest_filepath': args.dataset, 'labels': asr_model.decoder.vocabulary,
         'batch_size': args.batch_size, 'normalize_transcripts': args.normalize_text, 'shuffle': args.shuffle})
@@ -117,7 +121,12 @@ def main():
     served = type(getattr(asr_model, '_engine', None)).__name__
     print('path:', {'Engine': 'static integer engine (HIP)', 'DynamicRunner': 'dynamic device path (HIP)'}.get(
         served, 'host modules'))
-    print('WER:', word_error_rate(hypotheses=hyps, references=refs))
+    wer_value = word_error_rate(hypotheses=hyps, references=refs)
+    print('WER:', wer_value)
+    if args.dump_hyps:
+        import json
+        with open(args.dump_hyps, 'w') as f:
+            json.dump(dict(hypotheses=hyps, references=refs, wer=wer_value, path=served), f)
     print(f'RTFx (incl. host data loading): {audio_s / max(wall, 1e-9):.1f}  ({audio_s:.1f} s audio in {wall:.2f} s)')
 
 

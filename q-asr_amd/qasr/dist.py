@@ -27,6 +27,16 @@ def broadcast_bytes(data, src: int, device):
     return data if rank == src else buf.cpu().numpy().tobytes()
 
 
+def broadcast_blob(blob, src: int, device):
+    """The packed model from the calibrating rank to every rank; a receiving rank validates it (qasr_blob_check: every
+    offset, index and shape, host-only) before it may reach an engine."""
+    data = broadcast_bytes(blob, src, device)
+    if dist.get_rank() != src:
+        from . import engine
+        engine.blob_check(data)
+    return data
+
+
 def broadcast_tensors(tensors, src: int, device):
     """Broadcast a list of float tensors whose shapes are known on every rank."""
     out = []

@@ -9,7 +9,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('QASR_LIB', os.path.join(HERE, 'libqasr_hip.so'))   # QASR_LIB: A/B builds in one run
 
-SYMBOLS = ['qasr_engine_create', 'qasr_engine_create_ex', 'qasr_engine_default_opts', 'qasr_engine_destroy', 'qasr_engine_forward', 'qasr_engine_forward_audio', 'qasr_engine_out_frames',
+SYMBOLS = ['qasr_blob_check', 'qasr_engine_create', 'qasr_engine_create_ex', 'qasr_engine_default_opts', 'qasr_engine_destroy', 'qasr_engine_forward', 'qasr_engine_forward_audio', 'qasr_engine_out_frames',
            'qasr_engine_num_ops', 'qasr_engine_num_launches', 'qasr_engine_read_acc', 'qasr_engine_read_tensor', 'qasr_engine_last_op_ms',
            'qasr_engine_time_ops', 'qasr_engine_run_op', 'qasr_engine_op_label',
            'qasr_frontend_mel', 'qasr_frontend_plan', 'qasr_frontend_mel_planned', 'qasr_frontend_frames',
@@ -60,6 +60,7 @@ def load_library():
                         'the quantised inference path has no CPU fallback')
     lib = C.CDLL(LIB_PATH)
     vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.qasr_blob_check.argtypes = [C.c_char_p, sz, C.c_char_p, sz]
     lib.qasr_engine_create.argtypes = [vp, sz, i32, i32, C.POINTER(vp)]
     lib.qasr_engine_create_ex.argtypes = [vp, sz, i32, C.POINTER(EngineOpts), C.POINTER(vp)]
     lib.qasr_engine_default_opts.argtypes = [C.POINTER(EngineOpts)]
@@ -109,6 +110,14 @@ def load_library():
 def _check(rc, what):
     if rc != 0:
         raise QasrError(f'{what} failed ({rc}): {load_library().qasr_last_error().decode()}')
+
+
+def blob_check(blob: bytes):
+    """qasr_blob_check: raises QasrError naming the first malformed field of a packed model (host-only, no GPU needed)."""
+    lib = load_library()
+    why = C.create_string_buffer(256)
+    if lib.qasr_blob_check(bytes(blob), len(blob), why, len(why)) != 0:
+        raise QasrError('malformed blob: ' + why.value.decode())
 
 
 def _stream_ptr(stream=None):

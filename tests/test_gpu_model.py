@@ -130,40 +130,112 @@ def _write_wav(path, x):
         w.writeframes((np.clip(x, -1, 1) * 32767).astype('<i2').tobytes())
 
 
-def test_cli_inference_runs(tmp_path):
-    """examples/asr/quantization/inference.py end to end on synthetic WAVs (no dataset / checkpoint ships)."""
+def _cli(tmp_path, extra, n_utt, samples, seed, text):
+    """Runs examples/asr/quantization/inference.py on synthetic WAVs (no dataset / checkpoint ships); returns the
+    manifest path, its stdout and the --dump_hyps record."""
     man = tmp_path / 'manifest.json'
-    audio = synth.make_audio(6, 24000, seed=1)
+    audio = synth.make_audio(n_utt, samples, seed=seed)
     with open(man, 'w') as f:
-        for i in range(6):
+        for i in range(n_utt):
             p = str(tmp_path / f'u{i}.wav')
-            _write_wav(p, audio[i, :24000 - 1000 * i])
-            f.write(json.dumps(dict(audio_filepath=p, duration=(24000 - 1000 * i) / 16000, text='hello world')) + '\n')
+            n = samples - 1000 * i
+            _write_wav(p, audio[i, :n])
+            f.write(json.dumps(dict(audio_filepath=p, duration=n / 16000, text=text)) + '\n')
     cli = os.path.join(ROOT, 'q-asr_amd', 'examples', 'asr', 'quantization', 'inference.py')
-    out = subprocess.run([sys.executable, cli, '--asr_model', 'QuartzNet15x5Base-En', '--synthetic_model', '--dataset',
-                          str(man), '--batch_size', '3', '--synthetic_calib', '2', '--percentile', '99.996',
-                          '--weight_bit', '8', '--act_bit', '8'], capture_output=True, text=True, timeout=600)
+    dump = tmp_path / 'hyps.json'
+    out = subprocess.run([sys.executable, cli, '--asr_model', 'QuartzNet15x5Base-En', '--synthetic_model', '--dataset', str(man),
+                          '--weight_bit', '8', '--act_bit', '8', '--dither', '0', '--dump_hyps', str(dump)] + extra,
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert 'WER:' in out.stdout and 'RTFx' in out.stdout
+    with open(dump) as f:
+        return str(man), out.stdout, json.load(f)
+
+
+def _expected_hypotheses(m, manifest, batch_size):
+    """What the CLI must print for `manifest`, computed WITHOUT EncDecCTCModel.forward's engine routing: (a) the HIP front-end's
+    features through the calibrated HOST modules (encoder + decoder in PyTorch: identical features -> identical integers ->
+    identical hypotheses) and (b) the host front-end in front of the same modules (features within 1e-4: nearly all characters)."""
+    from nemo.collections.asr.metrics.wer import WER, word_error_rate
+    m.preprocessor.featurizer.dither = 0.0
+    m.setup_test_data(test_data_config={'sample_rate': 16000, 'manifest_filepath': manifest, 'labels': m.decoder.vocabulary,
+                                        'batch_size': batch_size, 'normalize_transcripts': True, 'shuffle': False})
+    wer = WER(vocabulary=m.decoder.vocabulary)
+    labels_map = dict(enumerate(m.decoder.vocabulary))
+    hyps, hyps_host, refs = [], [], []
+    for batch in m.test_dataloader():
+        sig, n = batch[0].cuda().float(), batch[1].cuda()
+        for front, acc in ((m._frontend_hip, hyps), (lambda s, l: m.preprocessor(input_signal=s, length=l), hyps_host)):
+            feats, flen = front(sig, n)
+            e, _, sf = m.encoder(audio_signal=feats, length=flen)
+            acc += wer.ctc_decoder_predictions_tensor(m.decoder(encoder_output=e, encoder_output_scaling_factor=sf).argmax(-1))
+        refs += [''.join(labels_map[c] for c in row) for row in batch[2].cpu().numpy()]
+    return hyps, hyps_host, refs, word_error_rate(hypotheses=hyps, references=refs)
+
+
+def _char_agreement(a, b):
+    import difflib
+    return min(difflib.SequenceMatcher(None, x, y).ratio() for x, y in zip(a, b))
+
+
+def test_cli_inference_runs(tmp_path):
+    """examples/asr/quantization/inference.py end to end (inference.py:145-159): the hypotheses and the WER it reports equal
+    what the host modules decode from the same WAVs with the same calibration."""
+    man, stdout, rec = _cli(tmp_path, ['--batch_size', '3', '--synthetic_calib', '2', '--percentile', '99.996'], 6, 24000, 1,
+                            'hello world')
+    assert 'RTFx' in stdout and 'path: static integer engine (HIP)' in stdout and rec['path'] == 'Engine'
+    m = EncDecCTCModel.from_synthetic('QuartzNet15x5Base-En').cuda()
+    m.eval()
+    m.set_quant_bit(8, mode='weight')
+    m.set_quant_bit(8, mode='act')
+    qm.set_percentile(m, 99.996)
+    m.encoder.bn_folding()
+    qm.calibrate(m)
+    L = torch.tensor([500] * 3).cuda()
+    for c in synth.make_calibration(2, 3, 64, 500):
+        e, _, sf = m.encoder(audio_signal=torch.from_numpy(c).cuda(), length=L)
+        m.decoder(encoder_output=e, encoder_output_scaling_factor=sf)
+    qm.evaluate(m)
+    qm.set_dynamic(m, False)
+    hyps, hyps_host, refs, wer_value = _expected_hypotheses(m, man, 3)
+    assert len(rec['hypotheses']) == 6 and all(len(h) > 0 for h in hyps)           # a random-weight net still emits characters
+    assert rec['references'] == refs == ['hello world'] * 6
+    assert rec['hypotheses'] == hyps
+    assert rec['wer'] == wer_value and f'WER: {wer_value}' in stdout
+    assert _char_agreement(rec['hypotheses'], hyps_host) >= 0.9
 
 
 def test_cli_inference_dynamic(tmp_path):
     """BASELINE.json config 1: inference.py --dynamic, batch size 1 (no calibration data): the dynamic-quantisation
-    device path (qasr.dynamic) serves the forward passes."""
-    man = tmp_path / 'manifest.json'
-    audio = synth.make_audio(2, 20000, seed=2)
-    with open(man, 'w') as f:
-        for i in range(2):
-            p = str(tmp_path / f'd{i}.wav')
-            _write_wav(p, audio[i])
-            f.write(json.dumps(dict(audio_filepath=p, duration=20000 / 16000, text='a b')) + '\n')
-    cli = os.path.join(ROOT, 'q-asr_amd', 'examples', 'asr', 'quantization', 'inference.py')
-    out = subprocess.run([sys.executable, cli, '--asr_model', 'QuartzNet15x5Base-En', '--synthetic_model', '--dataset',
-                          str(man), '--batch_size', '1', '--dynamic', '--weight_bit', '8', '--act_bit', '8'],
-                         capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert 'WER:' in out.stdout
-    assert 'path: dynamic device path (HIP)' in out.stdout
+    device path (qasr.dynamic) serves the forward passes; its hypotheses / WER equal what the CPU oracle's dynamic mode
+    (quant_modules.py:149-167; pinned by the reference's own dynamic fixtures) decodes from the same features."""
+    from nemo.collections.asr.metrics.wer import WER, word_error_rate
+    from oracle import int_oracle as O
+    man, stdout, rec = _cli(tmp_path, ['--batch_size', '1', '--dynamic'], 2, 20000, 2, 'a b')
+    assert 'path: dynamic device path (HIP)' in stdout and rec['path'] == 'DynamicRunner'
+    m = EncDecCTCModel.from_synthetic('QuartzNet15x5Base-En').cuda()
+    m.eval()
+    m.set_quant_bit(8, mode='weight')
+    m.set_quant_bit(8, mode='act')
+    m.encoder.bn_folding()
+    qm.evaluate(m)
+    qm.set_dynamic(m, True)
+    _, hyps_host, refs, _ = _expected_hypotheses(m, man, 1)
+    cfg = topology.quartznet15x5()
+    net = O.OracleNet(topology.conv_plan(cfg), cfg, synth.make_state_dict(cfg, 0), None, None, 8, 8, dynamic=True,
+                      division_residue=True)
+    wer = WER(vocabulary=m.decoder.vocabulary)
+    hyps = []
+    for batch in m.test_dataloader():
+        feats, flen = m._frontend_hip(batch[0].cuda().float(), batch[1].cuda())
+        want = net.forward(feats.cpu().numpy(), [int(flen[0])])
+        hyps += wer.ctc_decoder_predictions_tensor(torch.from_numpy(np.asarray(want['tokens'])).long())
+    assert rec['references'] == refs == ['a b'] * 2
+    assert all(len(h) > 0 for h in hyps) and rec['hypotheses'] == hyps
+    wer_value = word_error_rate(hypotheses=hyps, references=refs)
+    assert rec['wer'] == wer_value and f'WER: {wer_value}' in stdout
+    # host modules on the GPU in dynamic mode: every range depends on PyTorch-ROCm's float division / min / max of the whole
+    # tensor and this random-weight net has tiny argmax margins (measured 0.8): a plausibility bound, the oracle is the check
+    assert _char_agreement(rec['hypotheses'], hyps_host) >= 0.6
 
 
 @pytest.mark.parametrize('fuse_norm,S', [(True, 40000), (False, 40000), (True, 100000)])
@@ -302,4 +374,29 @@ def test_bench_exchange_steps_on_a_one_rank_rccl_communicator():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 1 and line['n_ranks_seen'] == 1 and line['steps'] == 8
     assert 'RCCL blob broadcast + token gather' in line['config']['parallelism']
+    assert line['value'] > 0
+
+
+@pytest.mark.parametrize('gather', ['tokens', 'logits'])
+def test_bench_two_ranks_with_real_engines_gloo_rehearsal(gather):
+    """The N > 1 bench loop with REAL engines and 4 steps in flight per rank, two ranks (both on GPU 0 - the box has one -
+    exchange steps through gloo / host memory: QASR_BENCH_BACKEND=gloo).  A FRESH child process runs torch.distributed.run,
+    which spawns its ranks before anything touches the GPU.  Checked: both ranks counted, rank 1 built its engines from the
+    broadcast blob (equal digests; the receiving rank also ran qasr_blob_check), rank 0's slot of every stream's receive
+    buffers equals its local result, and what the gather delivered FROM RANK 1 equals rank 0's own recomputation of rank 1's
+    steps (rank 1's audio seeds) - tokens, and with --gather logits the float32 log-probs (north_star's wording)."""
+    env = dict(os.environ, QASR_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'QASR_BENCH_FORCE_DIST'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', '29547' if gather == 'tokens' else '29549', os.path.join(ROOT, 'bench.py'),
+                          '--gpus', '2', '--steps', '8', '--warmup', '2', '--no-cpu-baseline', '--gather', gather, '--check-gather'],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['n_ranks_seen'] == 2 and line['steps'] == 8
+    assert line['blob_digests_equal_across_ranks'] is True
+    assert line['gather_checked_ranks'] == [1]
+    assert line['config']['global_batch'] == 64 and line['config']['steps_in_flight'] == 4
+    assert ('logits gather' if gather == 'logits' else 'token gather') in line['config']['parallelism']
     assert line['value'] > 0

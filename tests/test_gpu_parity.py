@@ -590,6 +590,48 @@ def test_production_engine_full_size_against_oracle(eng, oracle_full_size, opts)
 
 
 @pytest.fixture(scope='module')
+def oracle_jasper_full_size(golden_dir):
+    """FakeQuantNet on Jasper10x5dr w8a8 (BASELINE.json config 4's net) at 4 utterances x 500 frames, ragged lengths:
+    full, one frame into the second 128-frame tile, inside the last 32-frame tile, odd."""
+    from oracle.fakequant_torch import FakeQuantNet
+    d, meta = _load(golden_dir, 'net_jasper_w8a8')
+    cfg = topology.jasper10x5dr()
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    B, T = 4, 500
+    x = synth.make_features(B, 64, T, 33)
+    lens = [500, 257, 471, 389]                                # after block 0's stride 2: 250, 129, 236, 195
+    net = FakeQuantNet(topology.conv_plan(cfg), cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    want = net.forward(x, lens)
+    blob, pm = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
+    return dict(x=x, lens=lens, want=want, blob=blob, pm=pm)
+
+
+@pytest.mark.parametrize('tile', [32, 128])
+def test_production_engine_jasper_full_size_against_oracle(eng, oracle_jasper_full_size, tile):
+    """The NON-debug engine on Jasper10x5dr at its real channel counts (k_dense2's `DBG = false` plain and block-end forms;
+    jasper.py:601-630,664-682) against the CPU oracle: final encoder codes, tokens, encoded lengths, log-probs (rtol 1e-4)."""
+    o = oracle_jasper_full_size
+    e = eng.Engine(o['blob'], 0, tile=tile)
+    logp, tokens, enc_len = e.forward(torch.from_numpy(o['x']).cuda(), torch.tensor(o['lens']))
+    torch.cuda.synchronize()
+    labels = e.op_labels()
+    d2 = [l[len('k_dense2<'):-1].split(', ') for l in labels if l.startswith('k_dense2<')]      # [MT, DBG, RES]
+    assert len(d2) >= 50 and all(a[1] == 'false' for a in d2), labels     # the 50 dense convs of blocks 1-10 + block 11, no hooks
+    assert sum(a[2] == 'true' for a in d2) == 10, labels                  # every block-end (dense residual) layer on the RES form
+    want = o['want']
+    wl = want['enc_len'].numpy()
+    assert np.array_equal(enc_len.cpu().numpy(), wl)
+    codes = e.read_tensor(o['pm']['dec_in'], 1024)
+    tk, lp = tokens.cpu().numpy(), logp.cpu().numpy()
+    for b in range(len(wl)):
+        n = int(wl[b])
+        assert np.array_equal(codes[b, :, :n], want['enc_codes'][b, :, :n].numpy().astype(np.int8)), b
+        assert np.array_equal(tk[b, :n], want['tokens'][b, :n].numpy()), b
+        np.testing.assert_allclose(lp[b, :n], want['log_probs'][b, :n].numpy(), rtol=1e-4, atol=5e-5)
+    e.close()
+
+
+@pytest.fixture(scope='module')
 def oracle_jasper_t300(golden_dir):
     """OracleNet on one utterance x 300 frames of Jasper10x5dr w8a8 (150 frames after block 0: 5 / 3 / 2 time tiles)."""
     d, meta = _load(golden_dir, 'net_jasper_w8a8')
