@@ -30,9 +30,12 @@ for p in (os.path.join(ROOT, 'q-asr_amd'), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# Steps in flight live on separate HIP streams.  GPU_MAX_HW_QUEUES is NOT set here any more: with 4 streams it changes nothing,
-# and what more streams do is measured in profiles/r03_v3_queue_experiments.txt (8 streams do get 8 live queues with the
-# variable at 16 - and are slower: 0.525 ms/step; 4 launch chains is the measured optimum at batch 32).
+# Steps in flight live on separate HIP streams, and those need hardware queues of their own: with the runtime's default
+# (4 queues per process) the first four torch streams of this process land pairwise on TWO queues - measured in round 4 by
+# dropping this line: the timed region's streams finished at 6.4 / 6.5 / 12.3 / 12.3 ms and the step took 0.617 ms instead of
+# 0.39 (gpurun_out -> profiles/r04_v1_no_hw_queues_experiment.json).  With 8 queues the four launch chains run side by side.  More
+# chains than 4 do not pay at batch 32 (profiles/r03_v3_queue_experiments.txt: 8 streams / 16 queues: 0.525 ms/step).
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 PEAK_INT8_OPS = 256 * 4 * 2048 * 2.4e9       # 256 CUs x 4 SIMDs x 1024 MAC/clk (v_mfma_i32_32x32x32_i8) x 2.4 GHz
 PEAK_HBM = 8.0e12
@@ -65,11 +68,8 @@ def parse_args(argv=None):
                          'less weight / halo / tap-row traffic per frame but 1/2, 1/4 of the work-groups (128: the plain '
                          'k_sep2 layers only, the rest stays on 64); 0 = 128 when more than one step is in flight, else 32')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel instead of replaying the captured hipGraph')
-    ap.add_argument('--whole-utterance', action='store_true', help='use the k_utt kernels (one work-group per utterance)')
     ap.add_argument('--streams', type=int, default=int(os.environ.get('QASR_BENCH_STREAMS', 0)),
                     help='independent steps in flight per GPU (each on its own HIP stream + engine arena); 0 = the config default')
-    ap.add_argument('--persistent', type=int, default=int(os.environ.get('QASR_BENCH_PERSISTENT', 0)),
-                    help='1: runs of separable layers as one persistent launch (one work-group per utterance)')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the extra measurements of BASELINE.json configs 3 / 4 and of config 2 with log-probs (N = 1 only)')
     ap.add_argument('--gather', choices=['tokens', 'logits'], default='tokens',
@@ -466,8 +466,7 @@ class Workload:
         from qasr import engine, synth
         args, dev, B = self.args, self.env['dev'], self.batch
         rank = self.env['rank'] if rank is None else rank
-        engs = [engine.Engine(self.blob, self.env['local'], whole_utterance=args.whole_utterance, tile=tile, graph=not args.no_graph,
-                              persistent=bool(args.persistent)) for _ in range(S)]      # qasr_engine_opts (include/qasr.h)
+        engs = [engine.Engine(self.blob, self.env['local'], tile=tile, graph=not args.no_graph) for _ in range(S)]   # qasr_engine_opts (include/qasr.h)
         # (experiment QASR_BENCH_HIPRI=1: streams beyond the 4 normal-priority hardware queues come from the high-priority pool)
         streams = [torch.cuda.Stream(device=dev, priority=(-1 if (j >= 4 and os.environ.get('QASR_BENCH_HIPRI')) else 0)) for j in range(S)]
         T_out = engs[0].out_frames(self.T_pad)
@@ -691,15 +690,15 @@ def run(args):
                                'decoder + greedy argmax' + (' [QASR_BENCH_BATCH override: NOT the BASELINE batch]' if w.batch_override else ''),
                    'global_batch': BATCH * world, 'seq_len': FRAMES, 'weights': 'random-init (qasr.synth, seed 0)',
                    'steps_in_flight': S, 'inputs': 'one audio batch per step in flight (different seeds)',
-                   'steps_in_flight_note': f'one {BATCH}-utterance launch chain per HIP stream; 4 chains is the measured optimum at batch 32 '
-                                           '(profiles/r03_v3_queue_experiments.txt: 8 live queues are slower)',
+                   'steps_in_flight_note': f'one {BATCH}-utterance launch chain per HIP stream (GPU_MAX_HW_QUEUES=8 so that each has a hardware '
+                                           'queue: without it 0.617 ms/step, profiles/r04_v1_no_hw_queues_experiment.json); 4 chains is the measured '
+                                           'optimum at batch 32 (profiles/r03_v3_queue_experiments.txt: 8 chains are slower)',
                    'log_probs': ('written in the timed step (the exchange gathers them)' if args.gather == 'logits' else
                                  'not written in the timed step (tokens and encoded lengths are; the reference forward also returns '
                                  'log-probs: 0.9 MB of stores per step - other_configs.quartznet_with_logp times that variant)'),
                    'hip_graph': not args.no_graph,
-                   'kernels': ('k_utt' if args.whole_utterance else
-                               'k_dense2 (128 output channels x 256 / 128 frames per work-group), k_dense, k_sep' if args.config == 'jasper' else
-                               f'k_mel, k_stem (normalisation + block 0), k_sep2 ({tile}-frame tiles; block 16: its dilation-2 form), k_dec') + (', persistent launch' if args.persistent else ''),
+                   'kernels': ('k_dense2 (128 output channels x 256 / 128 frames per work-group), k_dense, k_sep' if args.config == 'jasper' else
+                               f'k_mel, k_stem (normalisation + block 0), k_sep2 ({tile}-frame tiles; block 16: its dilation-2 form), k_dec'),
                    'parallelism': f'utterance-sharded x{world}' + (f', {"RCCL" if backend == "nccl" else backend} blob broadcast + {"token" if args.gather == "tokens" else "logits"} gather' if use_dist else ''),
                    'wer': 'not measurable here: no LibriSpeech / checkpoint in the image'},
     }
@@ -738,7 +737,7 @@ def run(args):
 
     if world == 1 and rank == 0:
         # ---- one step in flight (32-frame tiles): the latency view of the same workload ------------------------
-        if S > 1 and not args.whole_utterance:
+        if S > 1:
             lane1 = w.make_lane(1, 32)
             dt1, _, _ = w.timed(lane1, args.steps, args.warmup, gathered=False)
             result['single_stream_ms_per_step'] = 1e3 * dt1 / args.steps

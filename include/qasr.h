@@ -145,12 +145,13 @@ typedef struct qasr_engine qasr_engine;
  * (nemo/collections/asr/models/ctc_models.py:91-147, examples/asr/quantization/inference.py:105-136).
  * `debug` bit 0 keeps every intermediate tensor and int32 accumulator alive for qasr_engine_read_*;
  * bit 1 only records one HIP event per op on the launch stream (qasr_engine_last_op_ms), no other change;
- * bit 2 selects the whole-utterance kernels (k_utt: one work-group per utterance and layer, T <= 256 frames) instead of
- * the 32-frame tiles of k_sep - same results, meant for many steps in flight;
+ * bit 2 (round 1's whole-utterance kernels k_utt) is retired: refused with QASR_ERR_UNSUPPORTED;
  * bit 3 makes k_sep use 64-frame tiles (half the weight / halo traffic per frame and half as many work-groups per
  * launch: faster when several steps are in flight on separate streams, slower for a single step);
  * bit 4 replays the forward as a hipGraph: the second forward with the same shape and the same five buffer pointers is
- * captured, later ones are one hipGraphLaunch (a new pointer set or shape starts over; ignored with bits 0/1). */
+ * captured, later ones are one hipGraphLaunch (a new pointer set or shape starts over; ignored with bits 0/1).
+ * This entry keeps qasr_engine_opts.fuse_norm = 0: qasr_engine_forward_audio leaves the normalised log-mel in `feats`, as in
+ * rounds 1 / 2 (the fused normalisation is opt-in through qasr_engine_create_ex, whose default has it on). */
 int qasr_engine_create(const void* blob, size_t blob_bytes, int device, int debug, qasr_engine** out);
 void qasr_engine_destroy(qasr_engine* e);
 
@@ -160,8 +161,7 @@ void qasr_engine_destroy(qasr_engine* e);
  * Two engines in one process are configured independently of each other through this call.
  * Environment variables remain ONLY as A/B overrides for profiling runs of an unmodified caller, read once per create
  * call AFTER the options: QASR_TILE128=0|1 (128-frame tiles when tile_frames >= 64), QASR_RES_TILE128, QASR_DENSE_TILE128,
- * QASR_SEP_GEN=1|2, QASR_NO_FUSE, QASR_NO_FUSE_STEM, QASR_NO_FUSE_DEC, QASR_LEGACY_PW, QASR_UTT, QASR_WIDE_TILES,
- * QASR_PERSISTENT=0|1, QASR_NO_FUSE_NORM; QASR_SEP2_TUNE is a kernel-internal experiment knob (csrc/qasr_sep2_impl.h). */
+ * QASR_SEP_GEN=1|2, QASR_NO_FUSE, QASR_NO_FUSE_STEM, QASR_NO_FUSE_DEC, QASR_WIDE_TILES, QASR_NO_FUSE_NORM; QASR_SEP2_TUNE is a kernel-internal experiment knob (csrc/qasr_sep2_impl.h). */
 typedef struct qasr_engine_opts {
   uint32_t struct_size;
   uint32_t debug;              /* bit 0: keep every tensor + int32 accumulators (parity hooks); bit 1: one HIP event per op */
@@ -173,13 +173,12 @@ typedef struct qasr_engine_opts {
   int32_t fuse_stem;           /* block 0 (lengths, first-layer QuantAct, strided depthwise, 1x1) as one launch */
   int32_t fuse_decoder;        /* decoder conv + log-softmax + argmax + encoded lengths as one launch */
   int32_t graph;               /* replay the forward as one hipGraph launch (second call with the same buffers captures) */
-  int32_t whole_utterance;     /* k_utt kernels (one work-group per utterance and layer, T <= 256) */
+  int32_t retired_whole_utterance; /* round 1's k_utt kernels, removed in round 4: must be <= 0 */
   int32_t res_tile128;         /* block-end (residual) layers on 128-frame tiles too when tile_frames == 128 */
   int32_t dense_tile128;       /* Jasper's plain dense convs on 128-frame tiles when tile_frames >= 64 */
-  int32_t legacy_pw;           /* stand-alone 1x1 convs on the v1 kernel k_pw */
-  int32_t persistent;          /* runs of consecutive k_sep2 layers as ONE persistent launch (one work-group per utterance
-                                  walks the layers and both time tiles: no kernel boundary, no inter-work-group exchange);
-                                  meant for many steps in flight - a 32-utterance launch occupies 32 CUs */
+  int32_t retired_legacy_pw;   /* round 1's k_pw, removed in round 4: must be <= 0 */
+  int32_t retired_persistent;  /* round 3's persistent per-utterance launch (built, bit-exact, measured slower: DESIGN.md closed
+                                  routes), removed in round 4: must be <= 0.  The three retired fields keep the struct layout */
   int32_t fuse_norm;           /* qasr_engine_forward_audio with the fused block 0: normalize_batch folded into k_stem from
                                   per-tile sums k_mel writes (no k_norm launch; `feats` then holds the UN-normalised log-mel) */
   int32_t reserved[2];
@@ -212,7 +211,7 @@ int qasr_engine_forward_audio(qasr_engine* e, void* stream, const float* audio, 
 int qasr_engine_out_frames(const qasr_engine* e, int T);
 int qasr_engine_num_ops(const qasr_engine* e);
 /* kernel launches of the last forward with the current plan: encoder + decoder (80 for QuartzNet15x5 with the default
- * options, 7 with `persistent`) plus, after qasr_engine_forward_audio, the front-end's (k_mel; + k_norm when fuse_norm is
+ * options) plus, after qasr_engine_forward_audio, the front-end's (k_mel; + k_norm when fuse_norm is
  * off: 81 / 82); -1 before the first forward */
 int qasr_engine_num_launches(const qasr_engine* e);
 
@@ -220,7 +219,8 @@ int qasr_engine_num_launches(const qasr_engine* e);
  * value rint(conv_int) of QuantConv1d.int_conv (quant_modules.py:304) for op `op` (pane < 0: main conv). */
 int qasr_engine_read_acc(qasr_engine* e, int op, int pane, int32_t* host_out, size_t n_elems);
 /* read_tensor also serves a production (non-debug) engine for a tensor whose arena slot no later tensor reused - e.g.
- * the decoder's input, the final encoder codes - and refuses the others. */
+ * the decoder's input, the final encoder codes - and refuses the others.  Every engine refuses a tensor its launch plan
+ * never stores (a depthwise output inside the fused layer's launch, k_stem's intermediates, the float logits inside k_dec). */
 int qasr_engine_read_tensor(qasr_engine* e, int tensor, void* host_out, size_t n_bytes, int* T_out, int* Tp_out);
 /* average device time (ms) per op kind over the last forward, measured with HIP events (debug engines) */
 int qasr_engine_last_op_ms(qasr_engine* e, float* ms_per_op, int n_ops);

@@ -21,6 +21,9 @@ namespace qasr {
 #define DENSE2_NT 256
 #define DENSE2_CK 128                   /* input channels per staged chunk */
 #define DENSE2_XP (DENSE2_CK + 16)      /* LDS row pitch: 16-byte aligned rows, rows 36 banks apart */
+#ifndef DENSE2_PANE_TR
+#define DENSE2_PANE_TR 1                /* residual panes staged [tile][channel][frame] + transposing LDS reads (0: round 3's form) */
+#endif
 
 // rows [tf, tf + rows) x channels [c0, c0 + 128) of x[B][cin][Tp] -> Xs[row][channel] (4 x 4 byte transposes; a task = 16
 // frames of 4 channels: four 16-byte loads, sixteen dword stores).  Frames outside [0, Tp) and channels >= cin read as code
@@ -228,9 +231,47 @@ __global__ void __launch_bounds__(DENSE2_NT, 2) k_dense2(SepP p) {
           for (int k = 0; k < 4; ++k) wq[k] = wp[64 * k];
         }
         __syncthreads();                                     // every wave has read the previous image
+        v4i ap[2][MT];
+#if DENSE2_PANE_TR
+        // A 1x1 conv needs no tap shifts, so its operand need not be K-contiguous in LDS: the chunk is staged as k_sep2 stages
+        // its residual operand - plain 16-byte copies of the [channel][frame] tensor into [tile][channel][32 frames] - and the A
+        // fragments come out of ds_read_b64_tr_b8.  (The [frame][channel] image costs four 16-byte loads, 16 v_perm and 16
+        // 4-way-conflicted ds_write_b32 per task and serves only 4 MT MFMAs per wave here, against 4 K MT in the main conv.)
+        {
+          constexpr int NGR = DENSE2_CK * 2 * MT, NGI = NGR / DENSE2_NT;   // 16-byte granules of the chunk, per thread
+          static_assert(NGR % DENSE2_NT == 0 && MT * DENSE2_CK * 32 <= (32 * MT) * DENSE2_XP, "pane image");
+          v4i g[NGI];
+#pragma unroll
+          for (int i = 0; i < NGI; ++i) {
+            const int gi = tid + DENSE2_NT * i, cc = gi / (2 * MT), q = gi - cc * (2 * MT);
+            const int ci = DENSE2_CK * c + cc, t = t0 + 16 * q;
+            g[i] = (ci < pn.cin && t < eTp) ? *(const v4i*)(pn.x + ((size_t)b * pn.cin + ci) * eTp + t) : (v4i){0, 0, 0, 0};
+          }
+#pragma unroll
+          for (int i = 0; i < NGI; ++i) {
+            const int gi = tid + DENSE2_NT * i, cc = gi / (2 * MT), q = gi - cc * (2 * MT);
+            v4i v = g[i];
+            v[0] ^= rflip; v[1] ^= rflip; v[2] ^= rflip; v[3] ^= rflip;
+            *(lds_v4i*)(Xs + (q >> 1) * (DENSE2_CK * 32) + cc * 32 + 16 * (q & 1)) = v;
+          }
+        }
+        __syncthreads();
+        const lds_u8* const pi_lane = Xs + sep2_a_lane_off(lane);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ap[0][mt] = sep2_a_frag(pi_lane + mt * (DENSE2_CK * 32), 0);
+        __builtin_amdgcn_sched_barrier(0);
+        sep2_for<0, 4>([&](auto ksc) {
+          constexpr int ks = decltype(ksc)::value;
+          sep2_for<0, MT>([&](auto mtc) {
+            constexpr int mt = decltype(mtc)::value;
+            accp[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ap[ks & 1][mt], wq[ks], accp[mt], 0, 0, 0);
+            if constexpr (ks + 1 < 4) ap[(ks + 1) & 1][mt] = sep2_a_frag(pi_lane + mt * (DENSE2_CK * 32), ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        });
+#else
         dense2_stage<MT>(Xs, pn.x, pn.cin, eTp, b, DENSE2_CK * c, t0, 32 * MT, rflip);
         __syncthreads();
-        v4i ap[2][MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) ap[0][mt] = *(const lds_v4i*)(a_lane + 32 * mt * DENSE2_XP);
         __builtin_amdgcn_sched_barrier(0);
@@ -243,6 +284,7 @@ __global__ void __launch_bounds__(DENSE2_NT, 2) k_dense2(SepP p) {
             __builtin_amdgcn_sched_barrier(0);
           });
         });
+#endif
       }
       if (DBG && pn.acc_dbg && co < ecout) {
 #pragma unroll

@@ -91,7 +91,6 @@ struct qasr_engine {
   std::vector<hipEvent_t> ev;          // debug timing: n_ops + 1 events
   bool timed = false;
   bool fuse = true;                    // fuse depthwise -> pointwise pairs into k_sep (QASR_NO_FUSE=1 disables)
-  bool legacy_pw = false;              // QASR_LEGACY_PW=1: stand-alone 1x1 convs through the v1 kernel k_pw
   std::vector<int> fused_dw;           // per op: index of the DW op fused into this PW op, or -1
   std::vector<char> skip;              // per op: launched as part of the following op
   bool fuse_stem = true;               // block 0 (lengths, first-layer quantisation, strided depthwise, 1x1) in one launch (QASR_NO_FUSE_STEM=1: four)
@@ -107,20 +106,12 @@ struct qasr_engine {
   std::vector<char> dec_skip;          // per op: LOGSOFTMAX op that ran inside the preceding decoder launch
   bool tile128 = true;                 // tile_frames == 128 (QASR_TILE128=0: k_sep2's plain layers stay on 64-frame tiles, A/B runs)
   bool res_tile128 = true;             // block-end layers on 128-frame tiles too (qasr_engine_opts.res_tile128)
-  bool persistent = false;             // runs of k_sep2 layers as one persistent launch (qasr_engine_opts.persistent)
   bool dense_tile128 = true;           // QASR_DENSE_TILE128=0 keeps Jasper's dense convs on 64-frame tiles (A/B runs)
   bool wide_tiles = false;             // k_sep with 64-frame tiles (throughput mode: bit 3 of `debug`, or QASR_WIDE_TILES=1)
-  bool use_utt = false;                // whole-utterance kernels k_utt (bit 2 of `debug`, or QASR_UTT=1)
   int sep_gen = 2;                     // 2: k_sep2 where it has the shape; 1 (QASR_SEP_GEN=1): k_sep everywhere (A/B runs)
-  std::vector<char> utt;               // per op: 0 = k_sep, 1 = k_utt plain, 2 = k_utt residual pair (rq32 + add32)
-  int32_t* r32 = nullptr;              // scratch [B][max cout][Tp] of the residual pair
   // hipGraph replay (bit 4 of `debug`): the whole forward of one (shape, buffer set) is captured once and re-launched
   // with one call; key = the caller's pointers, which a serving loop keeps stable
-  // persistent mode: runs of consecutive k_sep2 layers launched as one kernel (qasr_sep2_mega.hip)
-  struct MegaRun { uint32_t first = 0, last = 0; int n = 0; MegaOp* dev = nullptr; size_t smem = 0; };
-  std::vector<MegaRun> mega_runs;
-  std::vector<int> mega_of;            // per op: index into mega_runs, or -1
-  bool mega_built = false;
+  bool forwarded = false;              // a forward has been enqueued with the current plan
   bool use_graph = false;
   hipGraphExec_t gexec = nullptr;
   const void* gkey[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -155,8 +146,6 @@ static void free_plan(qasr_engine* e) {
   e->lens_all = nullptr;
   if (e->time_tokens) (void)hipFree(e->time_tokens);
   e->time_tokens = nullptr;
-  if (e->r32) (void)hipFree(e->r32);
-  e->r32 = nullptr;
   if (e->norm_stats) (void)hipFree(e->norm_stats);
   e->norm_stats = nullptr;
   e->norm_stats_bytes = 0;
@@ -167,11 +156,7 @@ static void free_plan(qasr_engine* e) {
   e->acc_dbg.clear();
   e->tens.clear();
   e->B = e->T0 = 0;
-  for (auto& r : e->mega_runs)
-    if (r.dev) (void)hipFree(r.dev);
-  e->mega_runs.clear();
-  e->mega_of.clear();
-  e->mega_built = false;
+  e->forwarded = false;
 }
 
 static int build_plan(qasr_engine* e, int B, int T0) {
@@ -267,37 +252,6 @@ static int build_plan(qasr_engine* e, int B, int T0) {
     e->ev.resize(h.n_ops + 1);
     for (auto& v : e->ev) HIPCHK(hipEventCreate(&v));
   }
-  e->utt.assign(h.n_ops, 0);
-  size_t r32_elems = 0;
-  if (e->use_utt && e->fuse)
-    for (uint32_t oi = 0; oi < h.n_ops; ++oi) {
-      const qasr_op_desc& q = e->ops[oi];
-      if (q.kind != QASR_OP_PW || (q.flags & QASR_F_LOGITS)) continue;
-      const TensorRT& o0 = e->tens[q.outs[0].tensor];
-      const int Tp = rup(o0.T, 64);
-      const int di = e->fused_dw[oi];
-      int K = 0, dil = 1;
-      if (di >= 0) {
-        K = (int)e->ops[di].kernel;
-        dil = (int)e->ops[di].dilation;
-      }
-      if (!utt_supported(K, dil, Tp, rup((int)q.cin, 128), (int)q.cin) || q.cout > 1024) continue;
-      bool ok = true;
-      if (q.flags & QASR_F_RESADD) {
-        if (q.n_panes != 1 || !utt_supported(0, 1, Tp, rup((int)q.panes[0].cin, 128), (int)q.panes[0].cin)) continue;
-        for (int j = 0; j < QASR_MAX_OUTS; ++j)
-          if (q.outs[j].tensor >= 0 && q.outs[j].mode != 0 && q.outs[j].mode != 2) ok = false;
-        if (!ok) continue;
-        e->utt[oi] = 2;
-        r32_elems = std::max(r32_elems, (size_t)B * q.cout * Tp);
-      } else {
-        for (int j = 0; j < QASR_MAX_OUTS; ++j)
-          if (q.outs[j].tensor >= 0 && q.outs[j].mode != 1) ok = false;
-        if (!ok) continue;
-        e->utt[oi] = 1;
-      }
-    }
-  if (r32_elems) HIPCHK(hipMalloc((void**)&e->r32, r32_elems * sizeof(int32_t)));
   e->B = B;
   e->T0 = T0;
   return QASR_OK;
@@ -387,9 +341,10 @@ int qasr_engine_create(const void* blob, size_t n, int device, int debug, qasr_e
   qasr_engine_opts o;
   qasr_engine_default_opts(&o);
   o.debug = (uint32_t)debug & 3u;
-  o.whole_utterance = (debug & 4) != 0;
+  if (debug & 4) return fail(QASR_ERR_UNSUPPORTED, "qasr_engine_create: bit 2 (k_utt) was retired in round 4");
   o.tile_frames = (debug & 8) ? 128 : 32;
   o.graph = (debug & 16) != 0;
+  o.fuse_norm = 0;       // callers of this entry read `feats` of qasr_engine_forward_audio as the NORMALISED log-mel (rounds 1 / 2)
   return qasr_engine_create_ex(blob, n, device, &o, out);
 }
 
@@ -405,6 +360,8 @@ int qasr_engine_create_ex(const void* blob, size_t n, int device, const qasr_eng
   if (o.tile_frames != 0 && o.tile_frames != 32 && o.tile_frames != 64 && o.tile_frames != 128)
     return fail(QASR_ERR_ARG, "qasr_engine_opts.tile_frames %d (0, 32, 64 or 128)", o.tile_frames);
   if (o.sep_gen < 0 || o.sep_gen > 2) return fail(QASR_ERR_ARG, "qasr_engine_opts.sep_gen %d (0, 1 or 2)", o.sep_gen);
+  if (o.retired_whole_utterance > 0 || o.retired_legacy_pw > 0 || o.retired_persistent > 0)
+    return fail(QASR_ERR_UNSUPPORTED, "qasr_engine_opts: whole_utterance / legacy_pw / persistent were retired in round 4 (include/qasr.h)");
   const int debug = (int)o.debug;
   {                                                          // every offset / index / shape of the blob, before any HIP call
     char why[256];
@@ -422,18 +379,14 @@ int qasr_engine_create_ex(const void* blob, size_t n, int device, const qasr_eng
   e->fuse_stem = tri(o.fuse_stem, true);
   e->fuse_dec = tri(o.fuse_decoder, true);
   e->fuse_norm = tri(o.fuse_norm, true);
-  e->legacy_pw = o.legacy_pw > 0;
   e->wide_tiles = o.tile_frames >= 64;
   e->tile128 = o.tile_frames == 128;
   e->res_tile128 = tri(o.res_tile128, true);
   e->dense_tile128 = tri(o.dense_tile128, true);
   e->sep_gen = o.sep_gen == 1 ? 1 : 2;
-  e->use_utt = o.whole_utterance > 0;                       // whole-utterance kernels (k_utt) are opt-in (throughput experiments)
   e->use_graph = o.graph > 0;
-  e->persistent = o.persistent > 0;
   // environment: A/B overrides for profiling runs of an unmodified caller (include/qasr.h lists them), read per create call
   if (getenv("QASR_NO_FUSE")) e->fuse = false;
-  if (getenv("QASR_LEGACY_PW")) e->legacy_pw = true;
   if (getenv("QASR_WIDE_TILES")) { e->wide_tiles = true; e->tile128 = true; }
   if (const char* g = getenv("QASR_TILE128")) e->tile128 = atoi(g) != 0;
   if (const char* g = getenv("QASR_RES_TILE128")) e->res_tile128 = atoi(g) != 0;
@@ -442,8 +395,6 @@ int qasr_engine_create_ex(const void* blob, size_t n, int device, const qasr_eng
   if (const char* g = getenv("QASR_NO_FUSE_NORM")) e->fuse_norm = atoi(g) == 0;
   if (const char* g = getenv("QASR_DENSE_TILE128")) e->dense_tile128 = atoi(g) != 0;
   if (const char* g = getenv("QASR_SEP_GEN")) e->sep_gen = atoi(g) == 1 ? 1 : 2;
-  if (getenv("QASR_UTT")) e->use_utt = true;
-  if (const char* g = getenv("QASR_PERSISTENT")) e->persistent = atoi(g) != 0;
   e->blob.assign((const uint8_t*)blob, (const uint8_t*)blob + n);
   e->h = h;
   e->tdesc = (const qasr_tensor_desc*)(e->blob.data() + h.tensors_off);
@@ -521,15 +472,11 @@ void qasr_engine_destroy(qasr_engine* e) {
 int qasr_engine_num_ops(const qasr_engine* e) { return e ? (int)e->h.n_ops : -1; }
 
 int qasr_engine_num_launches(const qasr_engine* e) {
-  if (!e || !e->B || !e->mega_built) return -1;
+  if (!e || !e->B || !e->forwarded) return -1;
   int n = (e->stem ? 0 : 1) + e->fe_launches;               // (k_lens, which the stem absorbs; front-end of forward_audio)
   for (uint32_t oi = 0; oi < e->h.n_ops; ++oi) {
-    if (e->mega_of[oi] >= 0) {
-      n += oi == e->mega_runs[e->mega_of[oi]].first;
-      continue;
-    }
     if (e->skip[oi] || e->dec_skip[oi] || e->rq_skip[oi] || (e->stem && oi >= 1 && oi <= 2)) continue;
-    n += (e->utt[oi] == 2) ? 2 : 1;
+    n += 1;
   }
   return n;
 }
@@ -543,7 +490,7 @@ int qasr_engine_out_frames(const qasr_engine* e, int T) {
   return dT[e->tdesc[last.in].domain];
 }
 
-// parameter block of the fused separable-layer kernels (k_sep / k_utt) for PW op `oi`
+// parameter block of the fused separable-layer kernels (k_sep2 / k_sep / k_dense2) for PW op `oi`
 static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
   const qasr_op_desc& op = e->ops[oi];
   const TensorRT& tin = e->tens[op.in];
@@ -557,6 +504,28 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
   p.gen = e->sep_gen;
   fill_panes(e, oi, op, p.panes);
   fill_epi(e, oi, op, p.e);
+  // the weight arrays the NEXT conv launch of the forward reads (prefetch hint of SEP2_PREFETCH builds; ignored otherwise)
+  for (uint32_t oj = oi + 1; oj < e->h.n_ops; ++oj) {
+    const qasr_op_desc& q = e->ops[oj];
+    if (q.kind == QASR_OP_DW && oj < e->skip.size() && e->skip[oj]) continue;      // runs inside the launch of op oj + 1
+    if (q.kind != QASR_OP_PW && !(q.kind == QASR_OP_DENSE && (q.flags & QASR_F_TAPMAJOR))) break;
+    auto lines = [](size_t bytes) { return (int)std::min<size_t>((bytes + 127) / 128, 1 << 14); };   // (at most 2 MiB per array)
+    const size_t cp = rup((int)q.cout, 128);
+    p.nx_ptr[0] = dev_w(e, q.w_off);
+    p.nx_lines[0] = lines(cp * rup((int)q.cin, 128) * (q.kind == QASR_OP_DENSE ? q.kernel : 1));
+    const int dj = oj < e->fused_dw.size() ? e->fused_dw[oj] : -1;
+    if (dj >= 0) {
+      const qasr_op_desc& d = e->ops[dj];
+      auto it = e->wexp2.find(d.w_off);
+      p.nx_ptr[1] = it != e->wexp2.end() ? (const void*)it->second : (const void*)dev_at<int8_t>(e, d.m_off);
+      p.nx_lines[1] = p.nx_ptr[1] ? lines((size_t)d.cout * (rup((int)d.kernel, 4) + 32)) : 0;
+    }
+    if (q.n_panes == 1) {
+      p.nx_ptr[2] = dev_w(e, q.panes[0].w_off);
+      p.nx_lines[2] = lines(cp * rup((int)q.panes[0].cin, 128));
+    }
+    break;
+  }
   const int di = e->fused_dw[oi];
   if (di >= 0) {
     const qasr_op_desc& d = e->ops[di];
@@ -635,7 +604,7 @@ static void build_dw(qasr_engine* e, uint32_t oi, DwP& p) {
 }
 // ops 0..2 = [first-layer QuantAct, strided depthwise conv, 1x1 conv], each feeding only the next: the stem k_stem runs
 static bool stem_shape(qasr_engine* e) {
-  if (e->h.n_ops < 3 || e->use_utt) return false;
+  if (e->h.n_ops < 3) return false;
   const qasr_op_desc &a = e->ops[0], &b = e->ops[1], &c = e->ops[2];
   if (a.kind != QASR_OP_QUANT_IN || b.kind != QASR_OP_DW || c.kind != QASR_OP_PW || e->skip[1] || e->fused_dw[2] >= 0) return false;
   if (b.in != a.outs[0].tensor || c.in != b.outs[0].tensor || a.outs[1].tensor >= 0 || b.outs[1].tensor >= 0) return false;
@@ -685,59 +654,17 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
       break;
     }
     case QASR_OP_PW: {
-      if (!e->legacy_pw || e->fused_dw[oi] >= 0) {
-        SepP p{};
-        build_sep(e, oi, p);
-        if (e->fuse_dec && (op.flags & QASR_F_LOGITS) && oi + 1 < e->h.n_ops && e->ops[oi + 1].kind == QASR_OP_LOGSOFTMAX &&
-            e->ops[oi + 1].in == op.outs[0].tensor && decoder_fusable(p)) {
-          int rc = launch_decoder(s, p, logp, tokens, lens_out, e->debug);
-          if (rc) return fail(rc, "op %u: decoder launch", oi);
-          e->dec_skip[oi + 1] = 1;
-          break;
-        }
-        if (e->utt[oi] == 1) {
-          launch_utt(s, p, 0);
-        } else if (e->utt[oi] == 2) {
-          // res_act as two whole-utterance launches: the residual 1x1 conv leaves rint(acc * M) in int32,
-          // the separable layer adds it in its epilogue (same arithmetic as the single-launch k_sep form)
-          SepP r{};
-          const PaneP& pn = p.panes[0];
-          r.x = pn.x;
-          r.w = pn.w;
-          r.bias = pn.bias;
-          r.cin = pn.cin;
-          r.cin_pad = pn.cin_pad;
-          r.pw_unsigned = pn.x_unsigned;
-          r.K = 0;
-          r.dilation = 1;
-          r.e = p.e;
-          r.e.sb = pn.sb;
-          r.e.m_main = pn.m;
-          r.e.acc_dbg = pn.acc_dbg;
-          r.e.n_outs = 1;
-          r.e.outs[0].ptr = e->r32;
-          r.e.outs[0].mode = 3;
-          launch_utt(s, r, 1);
-          p.r32 = e->r32;
-          p.n_panes = 0;
-          launch_utt(s, p, 2);
-        } else {
-          int rc = launch_sep(s, p);
-          if (rc) return fail(rc, "op %u: no k_sep instantiation for K=%d dilation=%d (or bad launch shape)", oi, p.K, p.dilation);
-        }
+      SepP p{};
+      build_sep(e, oi, p);
+      if (e->fuse_dec && (op.flags & QASR_F_LOGITS) && oi + 1 < e->h.n_ops && e->ops[oi + 1].kind == QASR_OP_LOGSOFTMAX &&
+          e->ops[oi + 1].in == op.outs[0].tensor && decoder_fusable(p)) {
+        int rc = launch_decoder(s, p, logp, tokens, lens_out, e->debug);
+        if (rc) return fail(rc, "op %u: decoder launch", oi);
+        e->dec_skip[oi + 1] = 1;
         break;
       }
-      PwP p{};
-      p.x = (const int8_t*)tin.ptr;
-      p.w = dev_w(e, op.w_off);
-      p.bias = dev_at<int32_t>(e, op.bias_off);
-      p.cin = (int)op.cin;
-      p.cin_pad = rup(p.cin, 128);
-      p.x_unsigned = tin.d.dtype == QASR_DT_U8;
-      p.n_panes = (int)op.n_panes;
-      fill_panes(e, oi, op, p.panes);
-      fill_epi(e, oi, op, p.e);
-      launch_pw(s, p);
+      int rc = launch_sep(s, p);
+      if (rc) return fail(rc, "op %u: no k_sep instantiation for K=%d dilation=%d (or bad launch shape)", oi, p.K, p.dilation);
       break;
     }
     case QASR_OP_DENSE: {
@@ -808,58 +735,6 @@ static int launch_op(qasr_engine* e, hipStream_t s, uint32_t oi, float* logp, in
   return QASR_OK;
 }
 
-// Persistent mode: maximal runs of consecutive ops the persistent kernel has a shape for (fused depthwise ops in between
-// run inside their 1x1 op's layer); a run of one layer gains nothing and stays a plain launch.  The parameter blocks hold
-// arena / blob pointers only (tensor 0, the caller's feature buffer, feeds the stem, never a separable layer), so they
-// are built once per plan.
-static int build_mega(qasr_engine* e) {
-  e->mega_built = true;
-  e->mega_of.assign(e->h.n_ops, -1);
-  if (!e->persistent || e->debug || e->timing || e->use_utt) return QASR_OK;
-  std::vector<MegaOp> cur;
-  std::vector<uint32_t> members;
-  uint32_t first = 0;
-  auto close = [&]() -> int {
-    if (cur.size() >= 2) {
-      qasr_engine::MegaRun r;
-      r.first = first;
-      r.last = members.back();
-      r.n = (int)cur.size();
-      for (const MegaOp& m : cur) r.smem = std::max(r.smem, sep2_mega_smem(m.p));
-      HIPCHK(hipMalloc((void**)&r.dev, cur.size() * sizeof(MegaOp)));
-      HIPCHK(hipMemcpy(r.dev, cur.data(), cur.size() * sizeof(MegaOp), hipMemcpyHostToDevice));
-      for (uint32_t oi = r.first; oi <= r.last; ++oi) e->mega_of[oi] = (int)e->mega_runs.size();
-      e->mega_runs.push_back(r);
-    }
-    cur.clear();
-    members.clear();
-    return QASR_OK;
-  };
-  for (uint32_t oi = 0; oi < e->h.n_ops; ++oi) {
-    if (e->skip[oi] && !cur.empty()) continue;               // a depthwise op fused into the next op: inside the run
-    int shape = -1;
-    MegaOp m{};
-    if (!e->skip[oi] && !(e->stem && oi <= 2) && e->ops[oi].kind == QASR_OP_PW && e->fused_dw[oi] >= 0) {
-      build_sep(e, oi, m.p);
-      m.p.prof = nullptr;
-      m.p.prof_mode = 0;
-      shape = sep2_mega_shape(m.p);
-    }
-    if (shape < 0) {
-      if (!e->skip[oi]) {
-        int rc = close();
-        if (rc) return rc;
-      }
-      continue;
-    }
-    if (cur.empty()) first = e->fused_dw[oi] >= 0 ? (uint32_t)e->fused_dw[oi] : oi;
-    m.shape = shape;
-    cur.push_back(m);
-    members.push_back(oi);
-  }
-  return close();
-}
-
 // front-end of a forward_audio call (nullptr: the caller's features are the input)
 struct FrontArgs {
   const float* audio;
@@ -921,23 +796,12 @@ static int forward_impl(qasr_engine* e, hipStream_t s, const FrontArgs* fe, floa
     if (!e->stem) launch_lens(s, lens, e->lens_all, ddoms, (int)h.n_domains, B);   // (k_stem derives them itself)
     for (uint32_t oi = 0; oi < h.n_ops; ++oi) {
       if (e->timing) HIPCHK(hipEventRecord(e->ev[oi], s));
-      if (e->mega_of[oi] >= 0) {                             // a run of separable layers: one persistent launch at its first op
-        const qasr_engine::MegaRun& r = e->mega_runs[e->mega_of[oi]];
-        if (oi == r.first) {
-          int rc = launch_sep2_mega(s, r.dev, r.n, B, r.smem);
-          if (rc) return fail(rc, "persistent launch of ops %u..%u", r.first, r.last);
-        }
-        continue;
-      }
       int rc = launch_op(e, s, oi, logp, tokens, lens_out);
       if (rc) return rc;
     }
     return QASR_OK;
   };
-  if (!e->mega_built) {
-    int rc = build_mega(e);
-    if (rc) return rc;
-  }
+  e->forwarded = true;
   if (e->use_graph && s != nullptr && !e->timing && !e->debug) {   // the legacy default stream cannot be captured
     const void* key[8] = {feats, lens, logp, tokens, lens_out, fe ? fe->audio : nullptr, fe ? fe->audio_lens : nullptr,
                           fe ? fe->plan : nullptr};
@@ -1057,12 +921,6 @@ int qasr_engine_op_label(qasr_engine* e, int op, char* buf, size_t cap) {
     case QASR_OP_LOGSOFTMAX: name = "k_logsoftmax"; break;
     case QASR_OP_REQUANT: name = "k_requant"; break;
     case QASR_OP_PW:
-      if (e->legacy_pw && e->fused_dw[op] < 0) { name = "k_pw"; break; }
-      if (e->utt[op]) {
-        const int di = e->fused_dw[op];
-        snprintf(buf, cap, "k_utt<%d>%s", di >= 0 ? (int)e->ops[di].kernel : 0, e->utt[op] == 2 ? " x2 (rq32 + add32)" : "");
-        return QASR_OK;
-      }
       {
         SepP p{};
         build_sep(e, (uint32_t)op, p);
@@ -1101,6 +959,15 @@ int qasr_engine_read_acc(qasr_engine* e, int op, int pane, int32_t* host_out, si
 int qasr_engine_read_tensor(qasr_engine* e, int tensor, void* host_out, size_t n_bytes, int* T_out, int* Tp_out) {
   if (!e || tensor <= 0 || tensor >= (int)e->tens.size()) return fail(QASR_ERR_ARG, "read_tensor: bad tensor / no forward yet");
   const TensorRT& t = e->tens[tensor];
+  {                                                          // a tensor the launch plan never stores has no bytes to serve
+    const int pr = t.d.producer;
+    const bool in_launch = pr >= 0 && pr < (int)e->skip.size() && e->skip[pr];           // depthwise output inside the fused layer's launch
+    const bool in_stem = e->stem && pr >= 0 && pr <= 1;                                    // k_stem's intermediates
+    const bool in_dec = !e->debug && pr >= 0 && pr + 1 < (int)e->dec_skip.size() && e->dec_skip[pr + 1] &&
+                        (e->ops[pr].flags & QASR_F_LOGITS);                                // float logits inside k_dec
+    if (in_launch || in_stem || in_dec)
+      return fail(QASR_ERR_ARG, "read_tensor: tensor %d is never materialised by this plan (its producer, op %d, runs fused inside another launch)", tensor, pr);
+  }
   if (!e->debug) {                                           // production engines reuse arena slots: only a tensor nobody overwrote
     for (size_t i = 1; i < e->tens.size(); ++i)
       if ((int)i != tensor && e->tens[i].slot == t.slot && e->tens[i].d.producer > t.d.producer)

@@ -40,15 +40,6 @@ struct EpiP {
   int cout, B;
 };
 
-struct PwP {              // 1x1 conv (+ residual panes)
-  const int8_t* x;        // [B][cin][Tp]
-  const int8_t* w;        // [cout_pad][cin_pad]
-  const int32_t* bias;    // [cout_pad]
-  int cin, cin_pad, x_unsigned, n_panes;
-  PaneP panes[QASR_MAX_PANES];
-  EpiP e;
-};
-
 struct DwP {              // depthwise conv
   const int8_t* x;        // [B][C][Tp_in]
   const int8_t* w;        // [C][kpad]
@@ -85,22 +76,16 @@ struct SepP {             // fused separable layer: depthwise stencil -> QuantAc
   int cin, cin_pad, pw_unsigned, n_panes;
   int dense_k, gen;       // dense_k > 1: dense conv with that many taps (K == 0 kernels; `w` tap-major, `dilation` = tap spacing);
                           // gen: 2 = route to k_sep2 where it has the shape (engine default), else k_sep
-  const int32_t* r32;     // k_utt EP_ADD32: res_act operand rint(acc_res * M_res) of the block's residual conv
   long long* prof;        // diagnostics: s_memtime stamps of work-group (0,0,0), wave 0 (qasr_debug_prof)
   int prof_mode;          // 1 (qasr_debug_timeline): every work-group writes {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, shader cycles}
   int prof_cap;           // ... for work-groups below this count (the caller's buffer)
+  // k_sep2, SEP2_PREFETCH builds: weight arrays of the NEXT launch of this stream (1x1 slab, tap rows, residual slab) as
+  // (pointer, 128-byte lines); each work-group touches its share so that the next layer's first requests hit this XCD's L2
+  const void* nx_ptr[3];
+  int nx_lines[3], nx_pad_;
   PaneP panes[QASR_MAX_PANES];
   EpiP e;
 };
-
-// one layer of a persistent launch (qasr_sep2_mega.hip): k_sep2's parameter block + the shape to instantiate, in device memory
-struct MegaOp {
-  int shape, pad_[3];
-  SepP p;
-};
-int sep2_mega_shape(const SepP& p);                    // >= 0: the persistent kernel has this op's shape
-size_t sep2_mega_smem(const SepP& p);
-int launch_sep2_mega(hipStream_t s, const MegaOp* dev_ops, int n_ops, int B, size_t smem);
 
 // qasr_dense2.hip: Jasper's plain dense convs (no residual panes) on 128-channel x 256-frame work-groups
 bool dense2_takes(const SepP& p);
@@ -132,14 +117,11 @@ struct RequantP {         // stand-alone requant of a stored value towards n_out
 
 void launch_quant_in(hipStream_t s, const QuantInP& p);
 void launch_dw(hipStream_t s, const DwP& p);
-void launch_pw(hipStream_t s, const PwP& p);
 void launch_dense(hipStream_t s, const DenseP& p);
 bool sep_supported(int K, int dilation);
 int launch_sep(hipStream_t s, const SepP& p);      // QASR_OK, or QASR_ERR_UNSUPPORTED / QASR_ERR_ARG without launching
 void sep_kernel_label(const SepP& p, char* buf, size_t cap);
 int sep_tile_for(const SepP& p);
-bool utt_supported(int K, int dilation, int Tp, int cin_pad, int cin);
-void launch_utt(hipStream_t s, const SepP& p, int ep);   // ep: 0 plain, 1 rq32 (residual conv), 2 add32 (res_act)
 void launch_requant(hipStream_t s, const RequantP& p);
 void launch_logsoftmax(hipStream_t s, const float* logits, float* logp, int32_t* tokens, int rows, int ncls);
 // qasr_stem.hip: lengths + first-layer QuantAct + strided depthwise conv + 1x1 conv of block 0 as one launch

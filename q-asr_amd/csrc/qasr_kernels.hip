@@ -262,134 +262,6 @@ __device__ __forceinline__ void pw_dump_acc(int32_t* dbg, const v16i& a0, const 
     }
 }
 
-__global__ void __launch_bounds__(256) k_pw(PwP p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[PW_TT * PW_XP];
-  const EpiP& e = p.e;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int t0 = blockIdx.x * PW_TT, b = blockIdx.z;
-  const int co_l = 32 * wave + (lane & 31);              // channel within the 128 tile
-  const int co = blockIdx.y * PW_MT + co_l;              // < cout_pad
-  const bool co_ok = co < e.cout;
-
-  v16i acc0, acc1;
-  {
-    const int bv = p.bias[co];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = bv; acc1[r] = bv; }
-  }
-  pw_gemm(acc0, acc1, p.x, p.w, p.cin, p.cin_pad, e.Tp, p.x_unsigned, b, t0, co, smem);
-  pw_dump_acc(e.acc_dbg, acc0, acc1, b, co, e.cout, t0, h, e.T, e.Tp);
-
-  const int lim = (e.flags & QASR_F_MASK_OUT) ? min(e.lens[b], e.T) : e.T;
-
-  if (e.flags & QASR_F_LOGITS) {       // decoder: logits[b][t][co] = fl32(fl32(acc) * s_b[co])
-    if (co_ok) {
-      const float sb = e.sb[co];
-#pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int t = t0 + pw_t(ti, r, h);
-          if (t < e.T) e.logits[((size_t)b * e.T + t) * e.cout + co] = __fmul_rn((float)(ti ? acc1[r] : acc0[r]), sb);
-        }
-    }
-    return;
-  }
-
-  int z0[16], z1[16];                  // integer result handed to the consumers
-  if (e.flags & QASR_F_RESADD) {
-    // res_act (jasper.py:680-682, quant_utils.py:187-214): q = clamp(rq(out) + rq(res_i)) for each pane in order
-    const bool exact = e.flags & QASR_F_EXACT_Z;
-    const double Mm = e.m_main[co];
-    const float sbm = e.sb[co];
-    double d0[16], d1[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      d0[r] = requant_d(exact ? z_roundtrip(acc0[r], sbm, false) : acc0[r], Mm);
-      d1[r] = requant_d(exact ? z_roundtrip(acc1[r], sbm, false) : acc1[r], Mm);
-    }
-    for (int pi = 0; pi < p.n_panes; ++pi) {
-      const PaneP& pn = p.panes[pi];
-      const int bv = pn.bias[co];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] = bv; acc1[r] = bv; }
-      pw_gemm(acc0, acc1, pn.x, pn.w, pn.cin, pn.cin_pad, e.Tp, pn.x_unsigned, b, t0, co, smem);
-      pw_dump_acc(pn.acc_dbg, acc0, acc1, b, co, e.cout, t0, h, e.T, e.Tp);
-      const double Mp = pn.m[co];
-      const float sbp = pn.sb[co];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        double s0 = d0[r] + requant_d(exact ? z_roundtrip(acc0[r], sbp, false) : acc0[r], Mp);
-        double s1 = d1[r] + requant_d(exact ? z_roundtrip(acc1[r], sbp, false) : acc1[r], Mp);
-        d0[r] = fmin(fmax(s0, (double)e.qlo), (double)e.qhi);
-        d1[r] = fmin(fmax(s1, (double)e.qlo), (double)e.qhi);
-      }
-    }
-    const bool relu = e.flags & QASR_F_RELU;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int q0 = (int)d0[r], q1 = (int)d1[r];
-      z0[r] = relu ? max(q0, 0) : q0;
-      z1[r] = relu ? max(q1, 0) : q1;
-    }
-  } else {
-    const float sb = e.sb[co];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { z0[r] = epi_z(acc0[r], e, sb); z1[r] = epi_z(acc1[r], e, sb); }
-  }
-
-  // consumers: requantise, pack 4 consecutive time steps per dword, stage through LDS, store 16 B per lane
-  for (int j = 0; j < e.n_outs; ++j) {
-    const OutP& o = e.outs[j];
-    if (o.mode == 3) {                 // raw int32 (many-consumer values): scattered stores, rare path
-      if (co_ok) {
-        int* op = (int*)o.ptr + ((size_t)b * e.cout + co) * e.Tp + t0;
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            int tl = pw_t(ti, r, h);
-            op[tl] = (t0 + tl < lim) ? (ti ? z1[r] : z0[r]) : 0;
-          }
-      }
-      continue;
-    }
-    const double Mc = (o.mode == 1) ? o.mtab[co] : 0.0;
-    __syncthreads();                   // previous users of smem (MFMA operand reads / previous out) are done
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        int v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 4 * g + i;
-          const int tl = pw_t(ti, r, h);
-          const int z = ti ? z1[r] : z0[r];
-          v[i] = (t0 + tl < lim) ? out_value(z, o, Mc) : 0;
-        }
-        *(unsigned*)(smem + co_l * PW_OP + 32 * ti + 8 * g + 4 * h) = pack4(v[0], v[1], v[2], v[3]);
-      }
-    __syncthreads();
-    {
-      const int row = tid >> 1, half = tid & 1;          // 128 rows x 2 halves of 32 B
-      const int cor = blockIdx.y * PW_MT + row;
-      if (cor < e.cout) {
-        int8_t* dst = (int8_t*)o.ptr + ((size_t)b * e.cout + cor) * e.Tp + t0 + 32 * half;
-        const v4i* src = (const v4i*)(smem + row * PW_OP + 32 * half);
-        ((v4i*)dst)[0] = src[0];
-        ((v4i*)dst)[1] = src[1];
-      }
-    }
-  }
-}
-
-void launch_pw(hipStream_t s, const PwP& p) {
-  const int cout_pad = (p.e.cout + PW_MT - 1) / PW_MT * PW_MT;
-  dim3 g(p.e.Tp / PW_TT, cout_pad / PW_MT, p.e.B);
-  hipLaunchKernelGGL(k_pw, g, dim3(256), 0, s, p);
-}
-
 // ------------------------------------------------------------------------------------------------ dense conv (Jasper)
 // Correctness-first implicit GEMM: same tile/MFMA structure as k_pw, the K loop runs over (tap, ci) and the
 // X tile for tap k is the input shifted by k*dilation - padding (stride handled by the gather).  Staged with

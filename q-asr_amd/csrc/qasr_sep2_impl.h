@@ -208,7 +208,7 @@ __device__ __forceinline__ void sep2_for(F&& f) {
 // pipe runs a 32x32x32 MFMA for 32 cycles while the wave issues the slice's VALU instructions (the previous unit's
 // requantisation); sched_barrier keeps the compiler from gathering the slices behind the last MFMA.
 template <int MT, int N, int N0, int AB, class CB>
-__device__ __forceinline__ void sep2_gemm_cb(v16i (&acc)[MT], v4i (&wf)[16], const lds_u8* img_lane, int mt_stride,
+__device__ __forceinline__ void sep2_gemm_cb(v16i* __restrict__ acc, v4i (&wf)[16], const lds_u8* img_lane, int mt_stride,
                                              const v4i* __restrict__ r0, const v4i* __restrict__ r1, CB&& cb) {
   constexpr int NQ = 4 * N / AB;
   v4i a[2][MT][AB];
@@ -619,6 +619,12 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
 #ifndef SEP2_ILV
 #define SEP2_ILV 1
 #endif
+#ifndef SEP2_PREFETCH
+#define SEP2_PREFETCH 0                 /* 1: every work-group touches its share of the next layer's weights (L2 warm-up) */
+#endif
+#ifndef SEP2_TAIL1
+#define SEP2_TAIL1 0                    /* 1: the last GEMM unit of a plain layer is one 32-frame tile (shorter exposed epilogue) */
+#endif
   constexpr bool ILV = SEP2_ILV && (!RES || TT <= 64) && DIL == 1;   // (register budget of the block-end forms at 128 frames)
   v4i accs[ILV ? 2 : 1][NU];
   auto chunk = [&](auto chc) {
@@ -708,6 +714,24 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
     __syncthreads();
   }
   STAMP2();
+  // SEP2_PREFETCH: the next launch of this stream reads ~0.3 MB of weights no work-group of this XCD has touched since the
+  // previous forward (19 MB of weights per forward against 4 MiB of L2): its first requests - the tap rows of depthwise
+  // group 0, which stand between the work-group's start and its first MFMA - come from the Infinity Cache.  Work-groups
+  // wg, wg + 8, wg + 16 ... share an XCD (round-robin dispatch; a wrong guess costs speed only): each touches every
+  // (n / 8)-th 128-byte line of the next layer's arrays, one dword per lane, into a register nothing reads - issued HERE,
+  // a GEMM phase before the wave ends, so the requests are long back when the last stores leave.
+  unsigned nx_sink = 0;
+  if constexpr (SEP2_PREFETCH) {
+    const int nshare = max((int)(gridDim.x * gridDim.y) >> 3, 1), share = wg_id >> 3;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int l = share + nshare * tid;
+      if (l < p.nx_lines[r]) {
+        const char* a = (const char*)p.nx_ptr[r] + (size_t)l * 128;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(nx_sink) : "v"(a) : "memory");
+      }
+    }
+  }
 
   // ------------------------------------------------------------------------------------------ 1x1 GEMM passes of 256 channels
   const lds_u8* const xd_lane = Xd + sep2_a_lane_off(lane);
@@ -721,20 +745,25 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
   constexpr bool PIPED = !RES && (NP * (MT >= 2 ? 2 : 1) > 1);   // (sep2_shape_ok: plain layers have exactly one consumer)
   if constexpr (PIPED) {
     {
-      constexpr int MH = MT >= 2 ? MT / 2 : 1, NH = MT / MH, NUN = NP * NH;   // tiles per unit, units per pass, units
-      constexpr int AB = MH >= 2 ? 1 : 2, NSL = 4 * NG * MH, NV = 16 * MH, VPS = (NV + NSL - 1) / NSL;   // (AB: register budget at MH = 2)
+      // Units: a pass is split into NH units of MH frame tiles each.  SEP2_TAIL1: the LAST unit of the last pass is split once
+      // more into two single-tile units - the only requantise + pack + store nothing hides is then one 32-frame tile (16 values
+      // per lane, one 16-byte store) instead of two, and half as many bytes are outstanding when the wave ends.
+      constexpr int MH = MT >= 2 ? MT / 2 : 1, NH = MT / MH;
+      constexpr bool SPLIT = SEP2_TAIL1 && MH == 2;
+      constexpr int NUN0 = NP * NH, NUN = NUN0 + (SPLIT ? 1 : 0);
       const OutP& o0 = e.outs[0];
       const int olo = o0.lo, ohi = o0.hi;
       int8_t* const optr = (int8_t*)o0.ptr;
       v16i accs[2][MH];
       int q4[4];
       unsigned P[4];
-      // accumulator hooks and EXACT_Z of a finished unit (tiles mt0 .. mt0 + MH - 1 of pass ps)
-      auto unit_finish = [&](v16i (&a)[MH], int ps, int mt0) __attribute__((always_inline)) {
+      // accumulator hooks and EXACT_Z of a finished unit (tiles mt0 .. mt0 + mh - 1 of pass ps)
+      auto unit_finish = [&](v16i* a, int ps, int mt0, auto mhc) __attribute__((always_inline)) {
+        constexpr int mh = decltype(mhc)::value;
         const int co = 256 * ps + co_l;
         if (DBG && e.acc_dbg) {
 #pragma unroll
-          for (int mt = 0; mt < MH; ++mt)
+          for (int mt = 0; mt < mh; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int t = t0 + 32 * (mt0 + mt) + mfma32_row(r, h);
@@ -742,16 +771,24 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
             }
         }
         if (f_exact) {
-          if (sep2_any_wide<MH>(a)) {
+          int mx = a[0][0], mn = a[0][0];
 #pragma unroll
-            for (int mt = 0; mt < MH; ++mt)
+          for (int mt = 0; mt < mh; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              mx = max(max(mx, a[mt][r]), a[mt][r + 1]);
+              mn = min(min(mn, a[mt][r]), a[mt][r + 1]);
+            }
+          if (__any(mx >= (1 << 21) || mn < -(1 << 21))) {
+#pragma unroll
+            for (int mt = 0; mt < mh; ++mt)
 #pragma unroll
               for (int r = 0; r < 16; ++r) a[mt][r] = z_roundtrip(a[mt][r], pps[ps].sbm, f_relu);
           }
         }
       };
       // values [v0, v1) of a finished unit: requantise; a completed tile leaves as one 16-byte store per lane
-      auto unit_values = [&](v16i (&a)[MH], int ps, int mt0, auto v0c, auto v1c) __attribute__((always_inline)) {
+      auto unit_values = [&](v16i* a, int ps, int mt0, auto v0c, auto v1c) __attribute__((always_inline)) {
         constexpr int v0 = decltype(v0c)::value, v1 = decltype(v1c)::value;
         sep2_for<v0, v1>([&](auto vc) {
           constexpr int v = decltype(vc)::value, mt = v / 16, r = v % 16;
@@ -766,27 +803,32 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
           }
         });
       };
+      // (pass, first tile, tiles) of unit u
+      auto u_ps = [](int u) constexpr { return u < NUN0 ? u / NH : NP - 1; };
+      auto u_mh = [](int u) constexpr { return (SPLIT && u >= NUN0 - 1) ? 1 : MH; };
+      auto u_mt0 = [](int u) constexpr { return u < NUN0 ? (u % NH) * MH : (NH - 1) * MH + 1; };
       sep2_for<0, NUN>([&](auto uc) {
-        constexpr int u = decltype(uc)::value, ps = u / NH, hf = u % NH;
-        v16i (&cur)[MH] = accs[u & 1];
+        constexpr int u = decltype(uc)::value, ps = u_ps(u), mh = u_mh(u), mt0 = u_mt0(u);
+        constexpr int AB = mh >= 2 ? 1 : 2, NSL = 4 * NG * mh;   // (AB: register budget at two tiles per unit)
+        v16i* const cur = accs[u & 1];
 #pragma unroll
-        for (int mt = 0; mt < MH; ++mt)
+        for (int mt = 0; mt < mh; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) cur[mt][r] = pps[ps].bias;
         // the slab is re-requested with the next pass's rows of this wave while the pass's last unit multiplies
-        const v4i* const wnext = (hf == NH - 1 && ps + 1 < NP) ? w_frag(p.w, CIN_PAD, 256 * (ps + 1) + co_l, 0) : nullptr;
-        if constexpr (u > 0) unit_finish(accs[(u - 1) & 1], (u - 1) / NH, ((u - 1) % NH) * MH);
-        sep2_gemm_cb<MH, NG, 0, AB>(cur, wf, xd_lane + hf * MH * (CIN_PAD * 32), CIN_PAD * 32, nullptr, wnext, [&](auto qc) {
+        const v4i* const wnext = (u < NUN0 && u % NH == NH - 1 && ps + 1 < NP) ? w_frag(p.w, CIN_PAD, 256 * (ps + 1) + co_l, 0) : nullptr;
+        if constexpr (u > 0) unit_finish(accs[(u - 1) & 1], u_ps(u - 1), u_mt0(u - 1), std::integral_constant<int, u_mh(u - 1)>{});
+        sep2_gemm_cb<mh, NG, 0, AB>(cur, wf, xd_lane + mt0 * (CIN_PAD * 32), CIN_PAD * 32, nullptr, wnext, [&](auto qc) {
           if constexpr (u > 0) {
+            constexpr int NV = 16 * u_mh(u - 1), VPS = (NV + NSL - 1) / NSL;
             constexpr int q = decltype(qc)::value, v0 = q * VPS < NV ? q * VPS : NV, v1 = (q + 1) * VPS < NV ? (q + 1) * VPS : NV;   // q: MFMA slot
-            unit_values(accs[(u - 1) & 1], (u - 1) / NH, ((u - 1) % NH) * MH, std::integral_constant<int, v0>{},
-                        std::integral_constant<int, v1>{});
+            unit_values(accs[(u - 1) & 1], u_ps(u - 1), u_mt0(u - 1), std::integral_constant<int, v0>{}, std::integral_constant<int, v1>{});
           }
         });
         STAMP2();
       });
-      unit_finish(accs[(NUN - 1) & 1], NP - 1, (NH - 1) * MH);
-      unit_values(accs[(NUN - 1) & 1], NP - 1, (NH - 1) * MH, std::integral_constant<int, 0>{}, std::integral_constant<int, NV>{});
+      unit_finish(accs[(NUN - 1) & 1], NP - 1, u_mt0(NUN - 1), std::integral_constant<int, u_mh(NUN - 1)>{});
+      unit_values(accs[(NUN - 1) & 1], NP - 1, u_mt0(NUN - 1), std::integral_constant<int, 0>{}, std::integral_constant<int, 16 * u_mh(NUN - 1)>{});
       STAMP2();
     }
   }
@@ -902,6 +944,7 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
     STAMP2();
   }
   }
+  if constexpr (SEP2_PREFETCH) asm volatile("" ::"v"(nx_sink));   // (keeps the sink register reserved until here)
   if (stamp) p.prof[31] = nst;
   if (tline && wg_id < p.prof_cap) {
     long long* r = p.prof + 4 * (size_t)wg_id;

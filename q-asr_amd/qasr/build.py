@@ -6,10 +6,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), 'csrc')
-LIB = os.path.join(HERE, 'libqasr_hip.so')
+# QASR_BUILD_TAG=<tag> (experiments): objects under build/obj_<tag>, library qasr/libqasr_<tag>.so - load it with QASR_LIB
+TAG = os.environ.get('QASR_BUILD_TAG', '')
+LIB = os.path.join(HERE, f'libqasr_{TAG}.so' if TAG else 'libqasr_hip.so')
 SOURCES = ['qasr_kernels.hip', 'qasr_sep.hip', 'qasr_sep_t32.hip', 'qasr_sep_t32_dbg.hip', 'qasr_sep_t64.hip',
-           'qasr_sep_t64_dbg.hip', 'qasr_sep_t128.hip', 'qasr_sep2_t32.hip', 'qasr_sep2_t32_dbg.hip', 'qasr_sep2_t64.hip', 'qasr_sep2_t64_dbg.hip', 'qasr_sep2_t128.hip', 'qasr_sep2_t128_dbg.hip', 'qasr_sep2_mega.hip', 'qasr_dense2.hip',
-           'qasr_utt.hip', 'qasr_engine.hip', 'qasr_blob_check.cpp', 'qasr_frontend.hip', 'qasr_calib.hip', 'qasr_dynamic.hip', 'qasr_decoder.hip', 'qasr_stem.hip']
+           'qasr_sep_t64_dbg.hip', 'qasr_sep_t128.hip', 'qasr_sep2_t32.hip', 'qasr_sep2_t32_dbg.hip', 'qasr_sep2_t64.hip', 'qasr_sep2_t64_dbg.hip', 'qasr_sep2_t128.hip', 'qasr_sep2_t128_dbg.hip', 'qasr_dense2.hip',
+           'qasr_engine.hip', 'qasr_blob_check.cpp', 'qasr_frontend.hip', 'qasr_calib.hip', 'qasr_dynamic.hip', 'qasr_decoder.hip', 'qasr_stem.hip']
 
 
 def _headers():
@@ -34,12 +36,12 @@ def build_native(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
     extra = os.environ.get('QASR_HIPCC_FLAGS', '').split()          # experiments: -DSEP_WK=8 ...
     # one object per translation unit, compiled in parallel (the k_sep instantiations dominate), then one link
-    objdir = os.path.join(os.path.dirname(HERE), 'build', 'obj')
+    objdir = os.path.join(os.path.dirname(HERE), 'build', 'obj_' + TAG if TAG else 'obj')
     os.makedirs(objdir, exist_ok=True)
     objs = [os.path.join(objdir, os.path.splitext(os.path.basename(f))[0] + '.o') for f in srcs]
     stamp = os.path.join(objdir, '.flags')
     flags_now = ' '.join(extra)
-    if force or extra or not os.path.exists(stamp) or open(stamp).read() != flags_now:
+    if force or not os.path.exists(stamp) or open(stamp).read() != flags_now:
         todo = list(zip(srcs, objs))
     else:
         hdr_t = max(os.path.getmtime(h) for h in _headers())

@@ -42,7 +42,7 @@ class EngineOpts(C.Structure):
     """qasr_engine_opts (include/qasr.h): the launch-plan choices of one engine."""
     _fields_ = ([('struct_size', C.c_uint32), ('debug', C.c_uint32)] +
                 [(n, C.c_int32) for n in ('tile_frames', 'sep_gen', 'fuse_dw', 'fuse_stem', 'fuse_decoder', 'graph',
-                                          'whole_utterance', 'res_tile128', 'dense_tile128', 'legacy_pw', 'persistent', 'fuse_norm')] +
+                                          'retired_whole_utterance', 'res_tile128', 'dense_tile128', 'retired_legacy_pw', 'retired_persistent', 'fuse_norm')] +
                 [('reserved', C.c_int32 * 2)])
 
 
@@ -132,9 +132,9 @@ def _ptr(t):
 class Engine:
     """One packed model on one GPU (qasr_engine_*)."""
 
-    def __init__(self, blob: bytes, device=0, debug=False, timing=False, whole_utterance=False, wide_tiles=False,
+    def __init__(self, blob: bytes, device=0, debug=False, timing=False, wide_tiles=False,
                  graph=False, tile=None, sep_gen=None, fuse_dw=None, fuse_stem=None, fuse_decoder=None, res_tile128=None,
-                 dense_tile128=None, persistent=False, fuse_norm=None):
+                 dense_tile128=None, fuse_norm=None, legacy_create=False):
         """Options = qasr_engine_opts (include/qasr.h).  tile: frames per work-group (32 / 64 / 128; `wide_tiles=True` is the
         older spelling of 128); None leaves a choice at the engine's default."""
         lib = load_library()
@@ -155,10 +155,14 @@ class Engine:
                         ('res_tile128', res_tile128), ('dense_tile128', dense_tile128), ('fuse_norm', fuse_norm)):
             if v is not None:
                 setattr(o, name, int(bool(v)))
-        o.graph, o.whole_utterance, o.persistent = int(bool(graph)), int(bool(whole_utterance)), int(bool(persistent))
+        o.graph = int(bool(graph))
         self.opts = o
-        _check(lib.qasr_engine_create_ex(C.cast(buf, C.c_void_p), len(blob), device, C.byref(o), C.byref(self._h)),
-               'qasr_engine_create_ex')
+        if legacy_create:       # rounds 1 / 2 entry point: the option bits of its `debug` argument (include/qasr.h), nothing else
+            bits = o.debug | (8 if o.tile_frames == 128 else 0) | (16 if graph else 0)
+            _check(lib.qasr_engine_create(C.cast(buf, C.c_void_p), len(blob), device, bits, C.byref(self._h)), 'qasr_engine_create')
+        else:
+            _check(lib.qasr_engine_create_ex(C.cast(buf, C.c_void_p), len(blob), device, C.byref(o), C.byref(self._h)),
+                   'qasr_engine_create_ex')
         self.debug = debug
         self.n_ops = lib.qasr_engine_num_ops(self._h)
         hdr = np.frombuffer(blob[:40], dtype=np.uint32)

@@ -37,7 +37,7 @@ def test_struct_sizes_match_packer(tmp_path):
                      'sizeof(qasr_blob_header),sizeof(qasr_tensor_desc),sizeof(qasr_op_desc),sizeof(qasr_out),'
                      'sizeof(qasr_pane),sizeof(qasr_domain_desc),sizeof(qasr_sep_layer_args),'
                      'offsetof(qasr_sep_layer_args, outs),offsetof(qasr_sep_layer_args, racc),'
-                     'sizeof(qasr_engine_opts),offsetof(qasr_engine_opts, tile_frames),offsetof(qasr_engine_opts, persistent),'
+                     'sizeof(qasr_engine_opts),offsetof(qasr_engine_opts, tile_frames),offsetof(qasr_engine_opts, retired_persistent),'
                      'sizeof(qasr_dyn_view),offsetof(qasr_dyn_view, residue_hi));return 0;}\n')
     exe = tmp_path / 'probe'
     subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(probe), '-o', str(exe)], check=True)
@@ -51,7 +51,7 @@ def test_struct_sizes_match_packer(tmp_path):
     assert sizes[6] == ctypes.sizeof(engine.SepLayerArgs)
     assert sizes[7] == engine.SepLayerArgs.outs.offset and sizes[8] == engine.SepLayerArgs.racc.offset
     assert sizes[9] == ctypes.sizeof(engine.EngineOpts) == 64      # the engine's launch-plan options (qasr_engine_create_ex)
-    assert sizes[10] == engine.EngineOpts.tile_frames.offset and sizes[11] == engine.EngineOpts.persistent.offset
+    assert sizes[10] == engine.EngineOpts.tile_frames.offset and sizes[11] == engine.EngineOpts.retired_persistent.offset
     from qasr import dynamic                                  # a float tensor as integers x scales (+ division residue)
     assert sizes[12] == ctypes.sizeof(dynamic.DynView) and sizes[13] == dynamic.DynView.residue_hi.offset
 
@@ -63,7 +63,7 @@ def test_engine_opts_defaults_and_validation():
     lib.qasr_last_error.restype = ctypes.c_char_p
     o = engine.EngineOpts()
     lib.qasr_engine_default_opts(ctypes.byref(o))
-    assert o.struct_size == ctypes.sizeof(engine.EngineOpts) and o.tile_frames == 0 and o.sep_gen == 0 and o.persistent == 0
+    assert o.struct_size == ctypes.sizeof(engine.EngineOpts) and o.tile_frames == 0 and o.sep_gen == 0 and o.retired_persistent == 0
     assert (o.fuse_dw, o.fuse_stem, o.fuse_decoder, o.res_tile128, o.dense_tile128) == (-1,) * 5 and o.graph == 0
     h = ctypes.c_void_p()
     blob = ctypes.create_string_buffer(256)
@@ -72,6 +72,9 @@ def test_engine_opts_defaults_and_validation():
     assert lib.qasr_engine_create_ex(blob, 256, 0, ctypes.byref(o), ctypes.byref(h)) == 1 and b'tile_frames' in lib.qasr_last_error()
     o.tile_frames, o.struct_size = 128, 4096
     assert lib.qasr_engine_create_ex(blob, 256, 0, ctypes.byref(o), ctypes.byref(h)) == 1 and b'struct_size' in lib.qasr_last_error()
+    o.tile_frames, o.struct_size, o.retired_persistent = 128, ctypes.sizeof(engine.EngineOpts), 1   # a retired option is refused loudly
+    assert lib.qasr_engine_create_ex(blob, 256, 0, ctypes.byref(o), ctypes.byref(h)) == 4 and b'retired' in lib.qasr_last_error()
+    o.retired_persistent = 0
     o.struct_size = 16                                         # an older, shorter struct is accepted (then the blob is checked)
     assert lib.qasr_engine_create_ex(blob, 256, 0, ctypes.byref(o), ctypes.byref(h)) == 2 and b'magic' in lib.qasr_last_error()
     assert lib.qasr_engine_create_ex(blob, 256, 0, None, ctypes.byref(h)) == 2      # NULL options = defaults

@@ -400,3 +400,40 @@ def test_bench_two_ranks_with_real_engines_gloo_rehearsal(gather):
     assert line['config']['global_batch'] == 64 and line['config']['steps_in_flight'] == 4
     assert ('logits gather' if gather == 'logits' else 'token gather') in line['config']['parallelism']
     assert line['value'] > 0
+
+
+def test_legacy_create_keeps_normalised_feats_and_read_tensor_refuses_unstored(golden_dir):
+    """(a) An engine made through the rounds-1/2 entry qasr_engine_create keeps fuse_norm off: qasr_engine_forward_audio leaves
+    the NORMALISED log-mel in `feats` (= qasr_frontend_mel, what the reference calls processed_signal, features.py:334-397),
+    with the pad frames zero; a create_ex engine (fused normalisation) produces the same tokens.  (b) qasr_engine_read_tensor
+    refuses tensors the launch plan never stores - a depthwise output inside the fused layer's launch, k_stem's
+    intermediates - instead of returning stale arena bytes, and still serves the decoder's input."""
+    from qasr import engine, melbank, pack
+    from qasr.pack import OP_DW
+    d = np.load(os.path.join(golden_dir, 'net_quartznet_w8a8.npz'))
+    meta = json.loads(str(d['meta']))
+    cfg = topology.quartznet15x5()
+    blob, pm = pack.pack_model(cfg, synth.make_state_dict(cfg, meta['seed']), d['act_min'], d['act_max'], 8, 8)
+    fb = torch.from_numpy(melbank.mel_filterbank(16000, 512, 64, 0.0, 8000.0).astype(np.float32)).cuda().contiguous()
+    win = torch.hann_window(320, periodic=False).cuda()
+    S = 40000
+    audio = torch.from_numpy(synth.make_audio(3, S, seed=8)).cuda()
+    alen = torch.tensor([S, S - 9001, 4000], dtype=torch.int32).cuda()
+    plan = engine.frontend_plan(fb)
+    want_feats, want_len = engine.frontend_mel(audio, alen, fb, win, 0.97, 16)
+    e_old, e_new = engine.Engine(blob, 0, legacy_create=True), engine.Engine(blob, 0)
+    feats = torch.full_like(want_feats, 7.0)                    # garbage a kernel must overwrite, pad frames included
+    flen = torch.empty(3, dtype=torch.int32, device='cuda')
+    _, tk_old, _ = e_old.forward_audio(audio, alen, fb, win, plan, 0.97, 16, feats=feats, feat_lens=flen)
+    _, tk_new, _ = e_new.forward_audio(audio, alen, fb, win, plan, 0.97, 16)
+    torch.cuda.synchronize()
+    assert torch.equal(feats, want_feats) and torch.equal(flen, want_len)
+    assert torch.equal(tk_old, tk_new)
+    kinds, tens = pm['kinds'], pm['tensors']
+    fused_dw_out = next(i for i, t in enumerate(tens) if t['producer'] >= 3 and kinds[t['producer']] == OP_DW)
+    for tensor in (1, 2, fused_dw_out):                          # QUANT_IN output, block 0's depthwise output (k_stem), a fused dw output
+        with pytest.raises(engine.QasrError, match='never materialised'):
+            e_new.read_tensor(tensor, tens[tensor]['channels'])
+    assert e_new.read_tensor(pm['dec_in'], 1024).shape[1] == 1024
+    e_old.close()
+    e_new.close()

@@ -115,12 +115,12 @@ def test_requant_exact_z_golden(eng, golden_dir):
 
 
 # ---------------------------------------------------------------------------------- networks
-def _run_engine(eng, golden_dir, name, debug=True, whole_utterance=False, wide_tiles=False):
+def _run_engine(eng, golden_dir, name, debug=True, wide_tiles=False):
     d, meta = _load(golden_dir, name)
     cfg = _cfg(name)
     sd = synth.make_state_dict(cfg, meta['seed'])
     blob, pm = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], meta['wbit'], meta['abit'])
-    e = eng.Engine(blob, 0, debug=debug, whole_utterance=whole_utterance, wide_tiles=wide_tiles)
+    e = eng.Engine(blob, 0, debug=debug, wide_tiles=wide_tiles)
     x = synth.make_features(meta['batch'], cfg.feat_in, meta['frames'], meta['seed'])
     logp, tokens, enc_len = e.forward(torch.from_numpy(x).cuda(), torch.tensor(meta['lengths']))
     torch.cuda.synchronize()
@@ -136,8 +136,8 @@ def _site_dims(cfg):
     return dims
 
 
-KERNEL_FAMILIES = [dict(), dict(wide_tiles=True), dict(whole_utterance=True)]
-KERNEL_IDS = ['k_sep32', 'k_sep64', 'k_utt']
+KERNEL_FAMILIES = [dict(), dict(wide_tiles=True)]
+KERNEL_IDS = ['k_sep32', 'k_sep64']
 
 
 @pytest.mark.parametrize('family', KERNEL_FAMILIES, ids=KERNEL_IDS)
@@ -185,7 +185,6 @@ def test_bench_size_properties(eng, golden_dir):
     sd = synth.make_state_dict(cfg, meta['seed'])
     blob, _ = pack.pack_model(cfg, sd, d['act_min'], d['act_max'], 8, 8)
     e = eng.Engine(blob, 0, debug=False)
-    eu = eng.Engine(blob, 0, debug=False, whole_utterance=True)
     B, T = 32, 500
     x = torch.from_numpy(synth.make_features(B, 64, T, 11)).cuda()
     lens = torch.tensor([T - 7 * (i % 9) for i in range(B)])
@@ -193,9 +192,6 @@ def test_bench_size_properties(eng, golden_dir):
     tk1, el1, lp1 = tk1.cpu().numpy(), el1.cpu().numpy(), lp1.cpu().numpy()
     lp2, tk2, _ = e.forward(x, lens)
     assert np.array_equal(tk1, tk2.cpu().numpy()) and np.array_equal(lp1, lp2.cpu().numpy())
-    lpu, tku, _ = eu.forward(x, lens)                          # whole-utterance kernels: identical integers
-    assert np.array_equal(tk1, tku.cpu().numpy()) and np.array_equal(lp1, lpu.cpu().numpy())
-    eu.close()
     ew = eng.Engine(blob, 0, debug=False, wide_tiles=True)     # 64-frame tiles: identical integers
     lpw, tkw, _ = ew.forward(x, lens)
     assert np.array_equal(tk1, tkw.cpu().numpy()) and np.array_equal(lp1, lpw.cpu().numpy())
@@ -484,8 +480,8 @@ def test_requant_fast_path_adversarial(eng):
 
 # ---------------------------------------------------------------------------------- production shape
 GENERATIONS = [dict(gen=2), dict(gen=2, wide_tiles=True, tile128=0), dict(gen=2, wide_tiles=True, tile128=1), dict(gen=1),
-               dict(gen=1, wide_tiles=True), dict(gen=1, whole_utterance=True)]
-GEN_IDS = ['k_sep2_32', 'k_sep2_64', 'k_sep2_128', 'k_sep_32', 'k_sep_64', 'k_utt']
+               dict(gen=1, wide_tiles=True)]
+GEN_IDS = ['k_sep2_32', 'k_sep2_64', 'k_sep2_128', 'k_sep_32', 'k_sep_64']
 
 
 def _engine_gen(eng, blob, gen, tile128=None, wide_tiles=False, **kw):
@@ -514,7 +510,7 @@ def oracle_quartznet_t500(golden_dir):
 def test_quartznet_t500_every_accumulator(eng, oracle_quartznet_t500, family):
     """The production kernels at the production tile count (T = 500 -> 250 frames = 8 / 4 time tiles per utterance, halos
     crossing tile borders, a ragged utterance): EVERY conv accumulator of QuartzNet15x5 against the CPU oracle
-    (quant_modules.py:301-305), bit-exact, for both kernel generations, both tile sizes and the whole-utterance kernels."""
+    (quant_modules.py:301-305), bit-exact, for both kernel generations and every tile size."""
     o = oracle_quartznet_t500
     fam = dict(family)
     e = _engine_gen(eng, o['blob'], fam.pop('gen'), debug=True, **fam)
@@ -560,7 +556,7 @@ def oracle_full_size(request, golden_dir):
     return dict(x=x, lens=lens, want=want, blob=blob, pm=pm, wbit=wbit)
 
 
-@pytest.mark.parametrize('opts', [dict(tile=32), dict(tile=128), dict(tile=128, persistent=True)], ids=['tile32', 'tile128', 'persistent'])
+@pytest.mark.parametrize('opts', [dict(tile=32), dict(tile=128)], ids=['tile32', 'tile128'])
 def test_production_engine_full_size_against_oracle(eng, oracle_full_size, opts):
     """The NON-debug engine (production instantiations: pipelined depthwise stage, packed-code masks, no accumulator hooks)
     at full size, w8a8 and w6a6, against the CPU oracle: tokens, encoded lengths, log-probs (rtol 1e-4) and the final
@@ -573,9 +569,8 @@ def test_production_engine_full_size_against_oracle(eng, oracle_full_size, opts)
     assert not any('true' in l for l in labels), labels        # no debug instantiation anywhere
     tt = f", {opts['tile']}, 1>"
     assert sum(l.startswith('k_sep2<') and l.endswith(tt) for l in labels) >= 60, labels
-    # QuartzNet15x5: ~80 launches layer by layer; persistent: stem, blocks 1-15 as ONE launch, block 16, block 17, decoder
-    n_launch = e.num_launches()
-    assert (n_launch <= 6) if opts.get('persistent') else (78 <= n_launch <= 82), n_launch
+    n_launch = e.num_launches()                                # QuartzNet15x5: 80 launches, layer by layer
+    assert 78 <= n_launch <= 82, n_launch
     want = o['want']
     wl = want['enc_len'].numpy()
     assert np.array_equal(enc_len.cpu().numpy(), wl)
