@@ -21,9 +21,7 @@ namespace qasr {
 #define DENSE2_NT 256
 #define DENSE2_CK 128                   /* input channels per staged chunk */
 #define DENSE2_XP (DENSE2_CK + 16)      /* LDS row pitch: 16-byte aligned rows, rows 36 banks apart */
-#ifndef DENSE2_PANE_TR
-#define DENSE2_PANE_TR 1                /* residual panes staged [tile][channel][frame] + transposing LDS reads (0: round 3's form) */
-#endif
+
 
 // rows [tf, tf + rows) x channels [c0, c0 + 128) of x[B][cin][Tp] -> Xs[row][channel] (4 x 4 byte transposes; a task = 16
 // frames of 4 channels: four 16-byte loads, sixteen dword stores).  Frames outside [0, Tp) and channels >= cin read as code
@@ -211,52 +209,70 @@ __global__ void __launch_bounds__(DENSE2_NT, 2) k_dense2(SepP p) {
         for (int r = 0; r < 16; ++r) acc[mt][r] = rq_rint(wide ? z_roundtrip(acc[mt][r], sb, false) : acc[mt][r], Mm);
       }
     }
-    for (int pi = 0; pi < p.n_panes; ++pi) {
-      const PaneP& pn = p.panes[pi];
-      const int pcin_pad = pn.cin_pad;
-      const unsigned rflip = pn.x_unsigned ? 0x80808080u : 0u;
-      const int pbias = pn.bias[co];
-      const double Mp = pn.m[co];
-      const float sbp = f_exact ? pn.sb[co] : 1.0f;
+    // The panes are 1x1 convs: their operand needs no tap shifts, so a chunk of 128 input channels is staged as k_sep2
+    // stages its residual operand - plain 16-byte copies of the [channel][frame] tensor into [tile][channel][32 frames] - and
+    // the A fragments come out of ds_read_b64_tr_b8 (the [frame][channel] image of the main conv costs 16 v_perm and 16
+    // conflicted ds_write_b32 per task and would serve only 4 MT MFMAs per wave here).  A chunk is only 4 MT MFMAs per wave
+    // (512 matrix-pipe cycles) behind a global round trip of several thousand under load, and the pane tensors (up to ten
+    // earlier blocks' outputs, 12.6 MB each at batch 64) come from the Infinity Cache: the (pane, chunk) items are therefore
+    // software-pipelined - the weights and image granules of item i + 1 are requested before item i's MFMAs and land in
+    // registers meanwhile, the image alternates between two LDS buffers, one barrier per item.
+    {
+      constexpr int NGR = DENSE2_CK * 2 * MT, NGI = NGR / DENSE2_NT;     // 16-byte granules of a chunk image, per thread
+      constexpr int IMG = MT * DENSE2_CK * 32;                            // bytes of one image
+      static_assert(NGR % DENSE2_NT == 0, "pane image granules");   // (launch_dense2_v sizes the LDS for two images)
+      struct Item { v4i w[4]; v4i g[NGI]; };
+      // requests of item (pi, c): this wave's weight fragments of the chunk's 4 K steps + this thread's image granules
+      auto issue = [&](Item& it, int pi, int c) {
+        const PaneP& pn = p.panes[pi];
+        const v4i* wp = w_frag(pn.w, pn.cin_pad, co_row, 4 * c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) it.w[k] = wp[64 * k];
+#pragma unroll
+        for (int i = 0; i < NGI; ++i) {
+          const int gi = tid + DENSE2_NT * i, cc = gi / (2 * MT), q = gi - cc * (2 * MT);
+          const int ci = DENSE2_CK * c + cc, t = t0 + 16 * q;
+          // (unconditional load from a clamped address + select: a load under a branch is waited for on the spot)
+          const bool ok = ci < pn.cin && t < eTp;
+          const v4i v = *(const v4i*)(pn.x + ((size_t)b * pn.cin + (ok ? ci : 0)) * eTp + (ok ? t : 0));
+          it.g[i] = ok ? v : (v4i){0, 0, 0, 0};
+        }
+      };
+      int pbias = 0;
+      double Mp = 0.0;
+      float sbp = 1.0f;
       v16i accp[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accp[mt][r] = pbias;
-      for (int c = 0; c < pcin_pad / DENSE2_CK; ++c) {
-        v4i wq[4];                                           // requested in front of the staging: its latency runs under it
-        {
-          const v4i* wp = w_frag(pn.w, pcin_pad, co_row, 4 * c);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) wq[k] = wp[64 * k];
+      int pi = 0, c = 0, nc = p.n_panes > 0 ? p.panes[0].cin_pad / DENSE2_CK : 0, buf = 0;
+      auto step = [&](Item& cur, Item& nxt) {                 // one (pane, chunk) item; returns false behind the last one
+        const PaneP& pn = p.panes[pi];
+        if (c == 0) {                                          // a new pane: its per-channel parameters, fresh accumulators
+          pbias = pn.bias[co];
+          Mp = pn.m[co];
+          sbp = f_exact ? pn.sb[co] : 1.0f;
         }
-        __syncthreads();                                     // every wave has read the previous image
+        const unsigned rflip = pn.x_unsigned ? 0x80808080u : 0u;
+        lds_u8* const img = Xs + buf * IMG;
+#pragma unroll
+        for (int i = 0; i < NGI; ++i) {
+          const int gi = tid + DENSE2_NT * i, cc = gi / (2 * MT), q = gi - cc * (2 * MT);
+          v4i v = cur.g[i];
+          v[0] ^= rflip; v[1] ^= rflip; v[2] ^= rflip; v[3] ^= rflip;
+          *(lds_v4i*)(img + (q >> 1) * (DENSE2_CK * 32) + cc * 32 + 16 * (q & 1)) = v;
+        }
+        // the next item's requests, one item (a barrier + 4 MT MFMAs) ahead of their use
+        int npi = pi, ncc = c + 1;
+        if (ncc == nc) { npi = pi + 1; ncc = 0; }
+        const bool more = npi < p.n_panes;
+        if (more) issue(nxt, npi, ncc);
+        if (c == 0) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accp[mt][r] = pbias;
+        }
+        __syncthreads();                                       // this image is complete; every wave is done with the other one
+        const lds_u8* const pi_lane = img + sep2_a_lane_off(lane);
         v4i ap[2][MT];
-#if DENSE2_PANE_TR
-        // A 1x1 conv needs no tap shifts, so its operand need not be K-contiguous in LDS: the chunk is staged as k_sep2 stages
-        // its residual operand - plain 16-byte copies of the [channel][frame] tensor into [tile][channel][32 frames] - and the A
-        // fragments come out of ds_read_b64_tr_b8.  (The [frame][channel] image costs four 16-byte loads, 16 v_perm and 16
-        // 4-way-conflicted ds_write_b32 per task and serves only 4 MT MFMAs per wave here, against 4 K MT in the main conv.)
-        {
-          constexpr int NGR = DENSE2_CK * 2 * MT, NGI = NGR / DENSE2_NT;   // 16-byte granules of the chunk, per thread
-          static_assert(NGR % DENSE2_NT == 0 && MT * DENSE2_CK * 32 <= (32 * MT) * DENSE2_XP, "pane image");
-          v4i g[NGI];
-#pragma unroll
-          for (int i = 0; i < NGI; ++i) {
-            const int gi = tid + DENSE2_NT * i, cc = gi / (2 * MT), q = gi - cc * (2 * MT);
-            const int ci = DENSE2_CK * c + cc, t = t0 + 16 * q;
-            g[i] = (ci < pn.cin && t < eTp) ? *(const v4i*)(pn.x + ((size_t)b * pn.cin + ci) * eTp + t) : (v4i){0, 0, 0, 0};
-          }
-#pragma unroll
-          for (int i = 0; i < NGI; ++i) {
-            const int gi = tid + DENSE2_NT * i, cc = gi / (2 * MT), q = gi - cc * (2 * MT);
-            v4i v = g[i];
-            v[0] ^= rflip; v[1] ^= rflip; v[2] ^= rflip; v[3] ^= rflip;
-            *(lds_v4i*)(Xs + (q >> 1) * (DENSE2_CK * 32) + cc * 32 + 16 * (q & 1)) = v;
-          }
-        }
-        __syncthreads();
-        const lds_u8* const pi_lane = Xs + sep2_a_lane_off(lane);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) ap[0][mt] = sep2_a_frag(pi_lane + mt * (DENSE2_CK * 32), 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -264,43 +280,40 @@ __global__ void __launch_bounds__(DENSE2_NT, 2) k_dense2(SepP p) {
           constexpr int ks = decltype(ksc)::value;
           sep2_for<0, MT>([&](auto mtc) {
             constexpr int mt = decltype(mtc)::value;
-            accp[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ap[ks & 1][mt], wq[ks], accp[mt], 0, 0, 0);
+            accp[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ap[ks & 1][mt], cur.w[ks], accp[mt], 0, 0, 0);
             if constexpr (ks + 1 < 4) ap[(ks + 1) & 1][mt] = sep2_a_frag(pi_lane + mt * (DENSE2_CK * 32), ks + 1);
             __builtin_amdgcn_sched_barrier(0);
           });
         });
-#else
-        dense2_stage<MT>(Xs, pn.x, pn.cin, eTp, b, DENSE2_CK * c, t0, 32 * MT, rflip);
-        __syncthreads();
+        if (c + 1 == nc) {                                     // the pane's last chunk: d = clamp(d + rint(z_pane M_pane))
+          if (DBG && pn.acc_dbg && co < ecout) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ap[0][mt] = *(const lds_v4i*)(a_lane + 32 * mt * DENSE2_XP);
-        __builtin_amdgcn_sched_barrier(0);
-        sep2_for<0, 4>([&](auto ksc) {
-          constexpr int ks = decltype(ksc)::value;
-          sep2_for<0, MT>([&](auto mtc) {
-            constexpr int mt = decltype(mtc)::value;
-            accp[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ap[ks & 1][mt], wq[ks], accp[mt], 0, 0, 0);
-            if constexpr (ks + 1 < 4) ap[(ks + 1) & 1][mt] = *(const lds_v4i*)(a_lane + 32 * mt * DENSE2_XP + 32 * (ks + 1));
-            __builtin_amdgcn_sched_barrier(0);
-          });
-        });
-#endif
-      }
-      if (DBG && pn.acc_dbg && co < ecout) {
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int t = t0 + 32 * mt + mfma32_row(r, h);
-            if (t < eT) pn.acc_dbg[((size_t)b * ecout + co) * eTp + t] = accp[mt][r];
+              for (int r = 0; r < 16; ++r) {
+                const int t = t0 + 32 * mt + mfma32_row(r, h);
+                if (t < eT) pn.acc_dbg[((size_t)b * ecout + co) * eTp + t] = accp[mt][r];
+              }
           }
-      }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const bool wide = f_exact && any_wide(accp[mt]);
+          for (int mt = 0; mt < MT; ++mt) {
+            const bool wide = f_exact && any_wide(accp[mt]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          acc[mt][r] = med3i(acc[mt][r] + rq_rint(wide ? z_roundtrip(accp[mt][r], sbp, false) : accp[mt][r], Mp), qlo, qhi);
+            for (int r = 0; r < 16; ++r)
+              acc[mt][r] = med3i(acc[mt][r] + rq_rint(wide ? z_roundtrip(accp[mt][r], sbp, false) : accp[mt][r], Mp), qlo, qhi);
+          }
+        }
+        buf ^= 1;
+        pi = npi;
+        c = ncc;
+        if (more && ncc == 0) nc = p.panes[npi].cin_pad / DENSE2_CK;
+        return more;
+      };
+      Item ia, ib;
+      if (p.n_panes > 0) {
+        __syncthreads();                                       // every wave has read the main conv's last window
+        issue(ia, 0, 0);
+        while (step(ia, ib) && step(ib, ia)) {}
       }
     }
 #pragma unroll
@@ -404,7 +417,11 @@ bool dense2_takes(const SepP& p) { return dense2_common(p) && (dense2_plain(p) |
 // frame tiles per wave: the plain form takes up to 8 (Tp is a multiple of 64: 2, 4, 6 or 8), the block-end form 4 (2 for Tp = 64)
 static int dense2_mt(const SepP& p) {
   if (p.e.flags & QASR_F_RESADD) return p.e.Tp >= 128 ? 4 : 2;
-  return p.e.Tp >= 256 ? 8 : p.e.Tp / 32;
+  // 8 tiles (256 frames) per work-group: a weight fragment feeds 8 MFMAs - the cheapest frame, for several steps in flight
+  // (Jasper bs64: 4.54 vs 4.78 ms/step); an engine built for ONE step in flight (32-frame tiles elsewhere) takes 4: twice the
+  // work-groups per launch fill the chip better than the weight reuse pays (5.49 vs 5.93 ms/step; profiles/r04_v4_jasper_ops*.txt)
+  const int cap = (p.etile > 0 && p.etile <= 32) ? 4 : 8;
+  return std::min(cap, p.e.Tp >= 256 ? 8 : p.e.Tp / 32);
 }
 
 void dense2_label(const SepP& p, char* buf, size_t cap) {
@@ -415,7 +432,8 @@ void dense2_label(const SepP& p, char* buf, size_t cap) {
 template <int MT, bool DBG, bool RES>
 static int launch_dense2_v(hipStream_t s, const SepP& p) {
   const int pad = p.dilation * (p.dense_k - 1) / 2, halo = (pad + 15) & ~15;
-  const size_t smem = (size_t)(32 * MT + 2 * halo) * DENSE2_XP;
+  size_t smem = (size_t)(32 * MT + 2 * halo) * DENSE2_XP;
+  if (RES) smem = std::max(smem, (size_t)2 * MT * DENSE2_CK * 32);      // two [tile][channel][32] pane images (double-buffered)
   if (!p.x || !p.w || !p.bias || !p.e.lens || p.e.B < 1 || p.e.cout < 1 || smem > 160 * 1024) return QASR_ERR_ARG;
   static int attr_dev = -1;
   int dev = 0;

@@ -500,6 +500,7 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
   p.cin_pad = rup(p.cin, 128);
   p.n_panes = (int)op.n_panes;
   p.tile = e->wide_tiles ? (e->tile128 ? 128 : 64) : 32;   // 128: k_sep2's separable layers only (sep2_tile), everything else 64
+  p.etile = p.tile;
   if (p.tile == 128 && !e->res_tile128 && (op.flags & QASR_F_RESADD)) p.tile = 64;
   p.gen = e->sep_gen;
   fill_panes(e, oi, op, p.panes);
