@@ -467,8 +467,13 @@ class Workload:
         args, dev, B = self.args, self.env['dev'], self.batch
         rank = self.env['rank'] if rank is None else rank
         engs = [engine.Engine(self.blob, self.env['local'], tile=tile, graph=not args.no_graph) for _ in range(S)]   # qasr_engine_opts (include/qasr.h)
-        # (experiment QASR_BENCH_HIPRI=1: streams beyond the 4 normal-priority hardware queues come from the high-priority pool)
-        streams = [torch.cuda.Stream(device=dev, priority=(-1 if (j >= 4 and os.environ.get('QASR_BENCH_HIPRI')) else 0)) for j in range(S)]
+        # The process keeps ONE set of HIP streams for every lane it builds (headline, one-step-in-flight, other_configs): which
+        # hardware queue a stream lands on is decided when it is created, and a later lane on fresh streams can find itself
+        # pairwise on shared queues (measured: the log-prob lane at 0.617 instead of 0.394 ms/step, gpurun_out r04_v5 first run)
+        pool = self.env.setdefault('streams', [])
+        while len(pool) < S:
+            pool.append(torch.cuda.Stream(device=dev))
+        streams = pool[:S]
         T_out = engs[0].out_frames(self.T_pad)
         audio = [torch.from_numpy(synth.make_audio(B, SAMPLES, seed=self.audio_seed(rank, k))).to(dev) for k in range(S)]
         ncls = engs[0].n_classes
