@@ -149,3 +149,33 @@ def test_committed_bench_lines_carry_the_contract_fields():
             assert k in cb, (f, k)
         assert cb['kind'] in ('port', 'reference') and cb['unit'] == r['unit']
         assert abs(r['value'] - r['n_gpus'] * 32 * 5.0 * (2 if 'bs64' in r['metric'] else 1) * r['steps'] / (r['ms_per_step'] * 1e-3 * r['steps'])) / r['value'] < 1e-3
+    # round 4: the driver's command also carries BASELINE.json's configurations 3 / 4 and the log-prob variant, measured after the
+    # headline region, and rocprofv3's own matrix-pipe counter for the dominant kernel (read from the committed *_pmc_MFMA.json)
+    drv = [f for f in lines if f.endswith('_bench_20.json')]
+    assert drv, lines
+    r = json.loads(open(drv[0]).read().strip().splitlines()[-1])
+    oc = r['other_configs']
+    assert set(oc) == {'quartznet_with_logp', 'w6a6', 'jasper'}
+    for k, v in oc.items():
+        assert v['steps'] == 20 and v['ms_per_step'] > 0 and 0 < v['step_mfma_frac'] < 1, (k, v)
+    assert oc['jasper']['roofline']['bound'] == 'mfma' and oc['w6a6']['baseline_config'] == 3 and oc['jasper']['baseline_config'] == 4
+    assert abs(oc['quartznet_with_logp']['ms_per_step'] / r['ms_per_step'] - 1) < 0.15      # writing log-probs costs (almost) nothing
+    busy = r['roofline']['other']['mfma_busy_frac_rocprof']
+    assert 0.2 < busy < 1.0 and r['roofline']['other']['rocprof_counters']['SQ_VALU_MFMA_BUSY_CYCLES'] > 0
+
+
+def test_pmc_mfma_summaries_are_calibrated():
+    """profiles/*_pmc_MFMA.json: rocprofv3's raw counters agree with the dominant kernel's known instruction stream - 64 work-groups
+    x 8 waves x (128 v_mfma_i32_32x32x32_i8 at 32 busy cycles + 672 v_mfma_i32_4x4x4 at 8) and 512 int8 operations per MOPS unit -
+    which is what makes the derived busy fraction a measurement and not a formula."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fs = sorted(glob.glob(os.path.join(root, 'profiles', 'r*_pmc_MFMA.json')))
+    assert fs
+    doc = json.load(open([f for f in fs if 'jasper' not in f][-1]))
+    row = doc['kernels']['qasr::k_sep2<75, 4, 0, 2, false, 128, 1>']
+    assert row['SQ_VALU_MFMA_BUSY_CYCLES'] == 64 * 8 * (128 * 32 + 672 * 8)
+    assert row['SQ_INSTS_VALU_MFMA_MOPS_I8'] * 512 == 64 * 8 * (128 * 2 * 32 ** 3 + 672 * 2 * 16 * 64)
+    assert row['SQ_INSTS_MFMA'] == 64 * 8 * 800 and row['SQ_LDS_UNALIGNED_STALL'] == 0
+    assert abs(row['mfma_busy_frac'] - row['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * row['SQ_BUSY_CU_CYCLES'])) < 1e-9
