@@ -353,6 +353,32 @@ def in_flight_timing(lane, roof, ops, reps=20):
                       'events recorded on those streams; effective = slowest stream\'s elapsed / all launches'}
 
 
+def cu_masked_stream(k, dev, parts=4):
+    """(experiment, QASR_BENCH_CU_MASK=1) A HIP stream whose queue may only use the k-th of `parts` disjoint sets of CUs
+    (hipExtStreamCreateWithCUMask).  On MI355X mask bit b is CU (b // 8) of XCC (b % 8) - profiles/r04_cu_mask_probe.txt - so bits
+    [64 k, 64 k + 64) are 8 CUs (two per shader engine) on every XCC: a 64-work-group launch of chain k then never competes
+    with the other chains' launches for CUs, and still has 8 work-groups per XCC."""
+    import ctypes as C
+    import torch
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+    hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    per = n_cu // parts
+    words = (n_cu + 31) // 32
+    arr = (C.c_uint32 * words)()
+    if os.environ.get('QASR_BENCH_CU_MASK') == 'xcc':          # whole XCCs per chain: XCC = b % 8; chain k owns XCCs 2 k, 2 k + 1
+        bits = [b for b in range(n_cu) if (b % 8) * parts // 8 == k % parts]
+    else:
+        bits = range(per * (k % parts), per * (k % parts + 1))
+    for b in bits:
+        arr[b // 32] |= 1 << (b % 32)
+    h = C.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), words, arr)
+    if rc:
+        raise SystemExit(f'hipExtStreamCreateWithCUMask failed ({rc})')
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 def build_model(device, model_name, wbit, abit):
     """Random-init model (no network for checkpoints), calibrated exactly like inference.py does."""
     import torch
@@ -472,7 +498,7 @@ class Workload:
         # pairwise on shared queues (measured: the log-prob lane at 0.617 instead of 0.394 ms/step, gpurun_out r04_v5 first run)
         pool = self.env.setdefault('streams', [])
         while len(pool) < S:
-            pool.append(torch.cuda.Stream(device=dev))
+            pool.append(cu_masked_stream(len(pool), dev) if os.environ.get('QASR_BENCH_CU_MASK') else torch.cuda.Stream(device=dev))
         streams = pool[:S]
         T_out = engs[0].out_frames(self.T_pad)
         audio = [torch.from_numpy(synth.make_audio(B, SAMPLES, seed=self.audio_seed(rank, k))).to(dev) for k in range(S)]
