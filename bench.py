@@ -482,6 +482,16 @@ class Workload:
         self.alen = torch.full((self.batch,), SAMPLES, dtype=torch.int32, device=dev)
         self.step_trace = [] if os.environ.get('QASR_BENCH_STEP_TRACE') else None   # (diagnostic) when each step finished
 
+    def with_batch(self, batch):
+        """The same model and blob with another number of utterances per launch (context measurements only)."""
+        import copy
+        import torch
+        w = copy.copy(self)
+        w.batch, w.batch_override = batch, True
+        w.lib_ws = self.lib.qasr_frontend_workspace_bytes(batch, SAMPLES, 64)
+        w.alen = torch.full((batch,), SAMPLES, dtype=torch.int32, device=self.env['dev'])
+        return w
+
     def audio_seed(self, rank, k):
         return 100 + 16 * rank + k
 
@@ -793,6 +803,22 @@ def run(args):
             for name in ('w6a6', 'jasper'):
                 oc[name] = measure_other_config(args, env, name, 20, 5)
             result['other_configs'] = oc
+            # context, NOT BASELINE's configuration 2: the same kernels when ONE launch has work-groups for the whole chip (four
+            # 32-utterance batches per launch, one chain) - a quarter of the kernel boundaries per utterance
+            w4 = w.with_batch(4 * BATCH)
+            lane4 = w4.make_lane(1, 128)
+            dt4, _, _ = w4.timed(lane4, 8, 2, gathered=False)
+            torch.cuda.synchronize()
+            r4 = dominant_kernel_roofline(lane4['engs'][0], cfg, w.meta, lane4['engs'][0].time_ops(reps=20).astype(np.float64), 4 * BATCH, FRAMES // 2)
+            result['roofline']['other']['four_batches_per_launch'] = {
+                'utterances_per_launch': 4 * BATCH, 'chains_in_flight': 1, 'ms_per_launch_chain': 1e3 * dt4 / 8,
+                'ms_per_32_utterances': 1e3 * dt4 / 8 / 4, 'kernel': r4['kernel'], 'work_groups_per_launch': r4['_wgs'],
+                'avg_launch_us': r4['avg_launch_us'], 'hbm_frac': r4['other']['hbm_frac'], 'mfma_frac': r4['other']['mfma_frac'],
+                'note': 'context only: batch 128 per launch is not BASELINE.json configuration 2 (bs32); it is what the dominant kernel '
+                        'and the step cost when a launch fills the chip by itself'}
+            for e_ in lane4['engs']:
+                e_.close()
+            log(f"four batches per launch (context): {result['roofline']['other']['four_batches_per_launch']['ms_per_32_utterances']:.3f} ms per 32 utterances")
         # ---- CPU baseline: the reference's fake-quant op sequence on this host's cores (N=1 only) --------------
         if not args.no_cpu_baseline:
             from oracle.fakequant_torch import FakeQuantNet
