@@ -505,28 +505,6 @@ static void build_sep(qasr_engine* e, uint32_t oi, SepP& p) {
   p.gen = e->sep_gen;
   fill_panes(e, oi, op, p.panes);
   fill_epi(e, oi, op, p.e);
-  // the weight arrays the NEXT conv launch of the forward reads (prefetch hint of SEP2_PREFETCH builds; ignored otherwise)
-  for (uint32_t oj = oi + 1; oj < e->h.n_ops; ++oj) {
-    const qasr_op_desc& q = e->ops[oj];
-    if (q.kind == QASR_OP_DW && oj < e->skip.size() && e->skip[oj]) continue;      // runs inside the launch of op oj + 1
-    if (q.kind != QASR_OP_PW && !(q.kind == QASR_OP_DENSE && (q.flags & QASR_F_TAPMAJOR))) break;
-    auto lines = [](size_t bytes) { return (int)std::min<size_t>((bytes + 127) / 128, 1 << 14); };   // (at most 2 MiB per array)
-    const size_t cp = rup((int)q.cout, 128);
-    p.nx_ptr[0] = dev_w(e, q.w_off);
-    p.nx_lines[0] = lines(cp * rup((int)q.cin, 128) * (q.kind == QASR_OP_DENSE ? q.kernel : 1));
-    const int dj = oj < e->fused_dw.size() ? e->fused_dw[oj] : -1;
-    if (dj >= 0) {
-      const qasr_op_desc& d = e->ops[dj];
-      auto it = e->wexp2.find(d.w_off);
-      p.nx_ptr[1] = it != e->wexp2.end() ? (const void*)it->second : (const void*)dev_at<int8_t>(e, d.m_off);
-      p.nx_lines[1] = p.nx_ptr[1] ? lines((size_t)d.cout * (rup((int)d.kernel, 4) + 32)) : 0;
-    }
-    if (q.n_panes == 1) {
-      p.nx_ptr[2] = dev_w(e, q.panes[0].w_off);
-      p.nx_lines[2] = lines(cp * rup((int)q.panes[0].cin, 128));
-    }
-    break;
-  }
   const int di = e->fused_dw[oi];
   if (di >= 0) {
     const qasr_op_desc& d = e->ops[di];

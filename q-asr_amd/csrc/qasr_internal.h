@@ -79,10 +79,6 @@ struct SepP {             // fused separable layer: depthwise stencil -> QuantAc
   long long* prof;        // diagnostics: s_memtime stamps of work-group (0,0,0), wave 0 (qasr_debug_prof)
   int prof_mode;          // 1 (qasr_debug_timeline): every work-group writes {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, shader cycles}
   int prof_cap;           // ... for work-groups below this count (the caller's buffer)
-  // k_sep2, SEP2_PREFETCH builds: weight arrays of the NEXT launch of this stream (1x1 slab, tap rows, residual slab) as
-  // (pointer, 128-byte lines); each work-group touches its share so that the next layer's first requests hit this XCD's L2
-  const void* nx_ptr[3];
-  int nx_lines[3];
   int etile;              // the engine's tile_frames option (32: built for one step in flight; 64 / 128: several), before per-op adjustments
   PaneP panes[QASR_MAX_PANES];
   EpiP e;

@@ -619,9 +619,6 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
 #ifndef SEP2_ILV
 #define SEP2_ILV 1
 #endif
-#ifndef SEP2_PREFETCH
-#define SEP2_PREFETCH 0                 /* 1: every work-group touches its share of the next layer's weights (L2 warm-up) */
-#endif
 #ifndef SEP2_TAIL1
 #define SEP2_TAIL1 0                    /* 1: the last GEMM unit of a plain layer is one 32-frame tile (shorter exposed epilogue) */
 #endif
@@ -714,25 +711,6 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
     __syncthreads();
   }
   STAMP2();
-  // SEP2_PREFETCH: the next launch of this stream reads ~0.3 MB of weights no work-group of this XCD has touched since the
-  // previous forward (19 MB of weights per forward against 4 MiB of L2): its first requests - the tap rows of depthwise
-  // group 0, which stand between the work-group's start and its first MFMA - come from the Infinity Cache.  Work-groups
-  // wg, wg + 8, wg + 16 ... share an XCD (round-robin dispatch; a wrong guess costs speed only): each touches every
-  // (n / 8)-th 128-byte line of the next layer's arrays, one dword per lane, into a register nothing reads - issued HERE,
-  // a GEMM phase before the wave ends, so the requests are long back when the last stores leave.
-  unsigned nx_sink = 0;
-  if constexpr (SEP2_PREFETCH) {
-    const int nshare = max((int)(gridDim.x * gridDim.y) >> 3, 1), share = wg_id >> 3;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int l = share + nshare * tid;
-      if (l < p.nx_lines[r]) {
-        const char* a = (const char*)p.nx_ptr[r] + (size_t)l * 128;
-        asm volatile("global_load_dword %0, %1, off" : "+v"(nx_sink) : "v"(a) : "memory");
-      }
-    }
-  }
-
   // ------------------------------------------------------------------------------------------ 1x1 GEMM passes of 256 channels
   const lds_u8* const xd_lane = Xd + sep2_a_lane_off(lane);
   const lds_u8* const xr_lane = Un + sep2_a_lane_off(lane);
@@ -944,7 +922,6 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
     STAMP2();
   }
   }
-  if constexpr (SEP2_PREFETCH) asm volatile("" ::"v"(nx_sink));   // (keeps the sink register reserved until here)
   if (stamp) p.prof[31] = nst;
   if (tline && wg_id < p.prof_cap) {
     long long* r = p.prof + 4 * (size_t)wg_id;
