@@ -28,6 +28,29 @@ def read_wav(path, target_sr=16000):
     return x
 
 
+def trim_silence(x, top_db=60.0, frame_length=2048, hop_length=512):
+    """Leading / trailing silence removed the way AudioSegment does with trim=True (segment.py:60-61:
+    `librosa.effects.trim(samples, 60)`): frame-wise RMS over centred frames (reflect padding) in dB relative to the loudest
+    frame; everything before the first / after the last frame above -top_db goes.  librosa is not importable here: restated
+    from its documented behaviour, parity unpinned."""
+    x = np.asarray(x, dtype=np.float32)
+    if x.size == 0:
+        return x
+    pad = frame_length // 2
+    xp = np.pad(x, pad, mode='reflect') if x.size > pad else np.pad(x, pad, mode='constant')
+    n_frames = 1 + (xp.size - frame_length) // hop_length
+    idx = np.arange(frame_length)[None, :] + hop_length * np.arange(n_frames)[:, None]
+    rms = np.sqrt(np.mean(xp[idx].astype(np.float64) ** 2, axis=1))
+    ref = rms.max()
+    if ref <= 0:
+        return x[:0]
+    db = 20.0 * np.log10(np.maximum(rms, 1e-10) / ref)       # amplitude_to_db(rms, ref=np.max, top_db=None)
+    keep = np.nonzero(db > -top_db)[0]
+    start = int(keep[0]) * hop_length
+    end = min(x.size, (int(keep[-1]) + 1) * hop_length)
+    return x[start:end]
+
+
 def normalize_text(text, vocabulary):
     """Normalised transcript as the reference's parser sees it (ENCharParser._normalize, parsers.py:136-145)."""
     from nemo.collections.asr.parts import parsers
@@ -37,10 +60,11 @@ def normalize_text(text, vocabulary):
 
 class AudioToCharDataset(Dataset):
     def __init__(self, manifest_filepath, labels, sample_rate=16000, normalize=True, max_duration=None,
-                 min_duration=None, **_unused):
+                 min_duration=None, trim=False, **_unused):
         self.labels = list(labels)
         self.index = {c: i for i, c in enumerate(self.labels)}
         self.sample_rate = sample_rate
+        self.trim = bool(trim)                               # `trim_silence` of the reference's dataset config (audio_to_text.py:228)
         self.items = []
         for path in str(manifest_filepath).split(','):
             with open(path) as f:
@@ -61,7 +85,10 @@ class AudioToCharDataset(Dataset):
 
     def __getitem__(self, i):
         path, text = self.items[i]
-        x = torch.from_numpy(read_wav(path, self.sample_rate))
+        x = read_wav(path, self.sample_rate)
+        if self.trim:
+            x = trim_silence(x)
+        x = torch.from_numpy(np.ascontiguousarray(x))
         t = torch.tensor([self.index[c] for c in text if c in self.index], dtype=torch.long)
         return x, torch.tensor(x.numel(), dtype=torch.long), t, torch.tensor(t.numel(), dtype=torch.long)
 
@@ -80,7 +107,8 @@ class AudioToCharDataset(Dataset):
 def make_dataloader(config):
     ds = AudioToCharDataset(config['manifest_filepath'], config['labels'], sample_rate=config.get('sample_rate', 16000),
                             normalize=config.get('normalize_transcripts', True),
-                            max_duration=config.get('max_duration'), min_duration=config.get('min_duration'))
+                            max_duration=config.get('max_duration'), min_duration=config.get('min_duration'),
+                            trim=config.get('trim_silence', False))
     return DataLoader(ds, batch_size=config['batch_size'], shuffle=config.get('shuffle', False),
                       collate_fn=AudioToCharDataset.collate_fn, drop_last=config.get('drop_last', False),
                       num_workers=config.get('num_workers', 0))

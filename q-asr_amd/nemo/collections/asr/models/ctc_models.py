@@ -147,6 +147,48 @@ class EncDecCTCModel(nn.Module):
     def test_dataloader(self):
         return self._test_dl
 
+    @torch.no_grad()
+    def transcribe(self, paths2audio_files, batch_size=4, logprobs=False):
+        """Greedy transcripts (or per-file log-probabilities) of audio files, in input order - the reference's debugging /
+        prototyping entry (ctc_models.py:148-212, 476-503): dither off and pad_to 0 for the duration of the call, evaluation
+        mode, a temporary manifest with `duration` 100000 and text 'nothing', batch size min(batch_size, #files), silence
+        trimmed (`trim_silence: True`), everything restored afterwards.  A calibrated model runs on the HIP engine."""
+        if paths2audio_files is None or len(paths2audio_files) == 0:
+            return {}
+        import json
+        import tempfile
+        from nemo.collections.asr.data.audio_to_text import make_dataloader
+        from nemo.collections.asr.metrics.wer import WER
+        hypotheses = []
+        mode = self.training
+        device = next(self.parameters()).device
+        f = self.preprocessor.featurizer
+        dither_value, pad_to_value = f.dither, f.pad_to
+        try:
+            f.dither, f.pad_to = 0.0, 0
+            self.eval()
+            with tempfile.TemporaryDirectory() as tmpdir:
+                manifest = os.path.join(tmpdir, 'manifest.json')
+                with open(manifest, 'w') as fp:
+                    for audio_file in paths2audio_files:
+                        fp.write(json.dumps({'audio_filepath': audio_file, 'duration': 100000, 'text': 'nothing'}) + '\n')
+                loader = make_dataloader({'manifest_filepath': manifest, 'sample_rate': 16000, 'labels': self.decoder.vocabulary,
+                                          'batch_size': min(batch_size, len(paths2audio_files)), 'trim_silence': True,
+                                          'shuffle': False})
+                wer = WER(vocabulary=self.decoder.vocabulary)
+                for batch in loader:
+                    logits, logits_len, greedy = self.forward(input_signal=batch[0].to(device).float(),
+                                                              input_signal_length=batch[1].to(device))
+                    if logprobs:
+                        for idx in range(logits.shape[0]):
+                            hypotheses.append(logits[idx][: logits_len[idx]])
+                    else:
+                        hypotheses += wer.ctc_decoder_predictions_tensor(greedy)
+        finally:
+            self.train(mode=mode)
+            f.dither, f.pad_to = dither_value, pad_to_value
+        return hypotheses
+
     # ------------------------------------------------------------------ engine path
     def _masked_convs(self):
         for blk in self.encoder.encoder_layers:

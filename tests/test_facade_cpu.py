@@ -406,3 +406,49 @@ def test_dynamic_runner_static_halves_on_cpu():
     wi, _ = Q.weight_integers(w, 6)
     assert c.dense and c.w.shape == (128, 5, 128) and int(wi.abs().max()) <= 31
     assert torch.equal(c.w[:32, :, :16].long(), wi.permute(0, 2, 1).long()) and int(c.w[32:].abs().sum()) == 0
+
+
+def test_transcribe_and_trim_silence(tmp_path):
+    """EncDecCTCModel.transcribe (ctc_models.py:148-212): transcripts in input order, per-file log-probs with `logprobs=True`,
+    dither / pad_to / training mode restored, {} for no files; and the `trim_silence` step of its data loader (segment.py:60-61:
+    librosa.effects.trim at 60 dB, restated - librosa is not importable, parity unpinned) on a signal with silent ends."""
+    import wave
+    from nemo.collections.asr.data.audio_to_text import trim_silence
+    rng = np.random.default_rng(3)
+    x = np.zeros(48000, np.float32)
+    x[10000:30000] = 0.1 * rng.standard_normal(20000)
+    y = trim_silence(x)
+    assert 20000 <= y.size <= 20000 + 2 * 2048 and np.abs(y).max() > 0
+    assert trim_silence(np.zeros(1000, np.float32)).size == 0
+    loud = 0.1 * rng.standard_normal(5000).astype(np.float32)
+    assert np.array_equal(trim_silence(loud), loud)
+
+    m = EncDecCTCModel.from_synthetic('MiniQuartzNet', seed=4)
+    m.set_quant_mode('none')                                   # float modules on the CPU (inference.py --no_quant)
+    m.train()
+    f = m.preprocessor.featurizer
+    f.dither, f.pad_to = 1e-5, 16
+    paths = []
+    for i, n in enumerate((16000, 9000, 12345)):
+        a = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        p = str(tmp_path / f't{i}.wav')
+        with wave.open(p, 'wb') as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes((np.clip(a, -1, 1) * 32767).astype('<i2').tobytes())
+        paths.append(p)
+    assert m.transcribe([]) == {} and m.transcribe(None) == {}
+    hyps = m.transcribe(paths, batch_size=2)
+    assert len(hyps) == 3 and all(isinstance(h, str) for h in hyps)
+    assert m.training and f.dither == 1e-5 and f.pad_to == 16    # everything restored
+    lps = m.transcribe(paths, batch_size=8, logprobs=True)
+    assert [tuple(t.shape)[1] for t in lps] == [29, 29, 29] and lps[0].shape[0] > lps[1].shape[0]
+    # File 0 is the longest of every batch it sat in: its row carries no pad frames and its STFT sees its own reflected end in both
+    # calls, so its transcript and its log-probs tell the same story.  (A SHORTER file's last frames and pad frames depend on the
+    # batch it sits in - the greedy decoder walks the whole padded row like the reference's, wer.py:117-136, and the centred STFT
+    # pads the batch tensor, not the utterance - so no such equality holds for files 1 and 2, here or in the reference.)
+    from nemo.collections.asr.metrics.wer import WER
+    again = WER(vocabulary=m.decoder.vocabulary).ctc_decoder_predictions_tensor(lps[0].argmax(-1).unsqueeze(0))
+    # (log-probs are cut at the encoded length, the transcript walks every frame the encoder emitted: at most a trailing token more)
+    assert hyps[0].startswith(again[0]) and len(hyps[0]) - len(again[0]) <= 2

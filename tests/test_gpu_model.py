@@ -437,3 +437,38 @@ def test_legacy_create_keeps_normalised_feats_and_read_tensor_refuses_unstored(g
     assert e_new.read_tensor(pm['dec_in'], 1024).shape[1] == 1024
     e_old.close()
     e_new.close()
+
+
+def test_transcribe_runs_on_the_engine(tmp_path):
+    """EncDecCTCModel.transcribe (ctc_models.py:148-212) of a calibrated model on the GPU: the forward passes go through the HIP
+    engine (front-end with pad_to 0 + integer encoder / decoder), transcripts come back in input order and equal what the
+    calibrated host modules decode from the same trimmed, padded batches through the same front-end features."""
+    from nemo.collections.asr.data.audio_to_text import AudioToCharDataset, read_wav, trim_silence
+    from nemo.collections.asr.metrics.wer import WER
+    m = _prepared_model('QuartzNet15x5Base-En', seed=5, percentile=99.996, feat=64, frames=128)
+    audio = synth.make_audio(3, 30000, seed=9)
+    paths = []
+    for i, n in enumerate((30000, 17000, 23456)):
+        a = audio[i, :n].copy()
+        a[:2000] = 0                                             # leading silence: trimmed away by the loader
+        p = str(tmp_path / f'x{i}.wav')
+        _write_wav(p, a)
+        paths.append(p)
+    hyps = m.transcribe(paths, batch_size=2)
+    assert type(m._engine).__name__ == 'Engine' and len(hyps) == 3
+    f = m.preprocessor.featurizer
+    assert f.pad_to == 16 and f.dither > 0                       # restored
+    f.dither, f.pad_to = 0.0, 0
+    wer = WER(vocabulary=m.decoder.vocabulary)
+    want = []
+    for group in (paths[:2], paths[2:]):
+        xs = [torch.from_numpy(np.ascontiguousarray(trim_silence(read_wav(p)))) for p in group]
+        assert all(x.numel() < 30000 - 1000 for x in xs[:1])     # the silent head is gone
+        sig = torch.zeros(len(xs), max(x.numel() for x in xs))
+        for i, x in enumerate(xs):
+            sig[i, :x.numel()] = x
+        n = torch.tensor([x.numel() for x in xs])
+        feats, flen = m._frontend_hip(sig.cuda(), n.cuda())
+        e, _, sf = m.encoder(audio_signal=feats, length=flen)
+        want += wer.ctc_decoder_predictions_tensor(m.decoder(encoder_output=e, encoder_output_scaling_factor=sf).argmax(-1))
+    assert hyps == want
