@@ -17,7 +17,7 @@ __device__ __forceinline__ int requant_clamp(int z, double M, int lo, int hi) {
   t = fmin(fmax(t, MAGIC_RNE + (double)lo), MAGIC_RNE + (double)hi);
   return __double2loint(t);
 }
-// Batches of values sharing a multiplier (k_sep / k_utt / k_requant epilogues).  Round 1 formed the product in float32
+// Batches of values sharing a multiplier (k_sep / k_requant epilogues).  Round 1 formed the product in float32
 // first and took the fp64 path only for a batch holding a value within tau of a rounding tie (54 cycles per value with
 // the wave vote); the round-2 micro-benchmarks (profiles/microbench/ubench.hip) put fp64 fma at the integer ALU's issue
 // rate on gfx950, which makes the exact form the cheap one (~20 cycles per value) - so that is all there is now.

@@ -257,7 +257,7 @@ struct Sep2PassP {
 // NP passes of 256 output channels - all compile-time: the whole kernel is straight-line code, which is what lets the
 // compiler count its s_waitcnt vmcnt(N) exactly instead of draining every prefetch at each join
 // The work of ONE work-group: utterance b, frames [t0, t0 + TT), every channel.  k_sep2 below runs it once per work-group
-// of a (B, Tp / TT) grid; the persistent kernel (qasr_sep2_mega.hip) walks layers and time tiles with it.  `p` may live
+// of a (B, Tp / TT) grid (round 3's persistent launch, removed since, walked layers and time tiles with it).  `p` may live
 // in the kernel-argument segment or in global memory: its address is wave-uniform either way (scalar loads).
 // DIL = 2 (QuartzNet's block 16, k = 87): out[t] = sum_m w[m] x[t - 86 + 2 m] only touches frames of t's parity, so every
 // channel is staged as TWO rows - its even and its odd frames - and each row sees an ordinary dilation-1 conv over TT / 2
@@ -282,7 +282,7 @@ __device__ __forceinline__ void sep2_body(const SepP& p, const int b, const int 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const EpiP& e = p.e;
   int tid_ = threadIdx.x;
-  // (persistent kernel: every lane-derived constant is recomputed inside the call - hoisted out of the layer loop they
+  // (kept from the persistent-launch experiment: every lane-derived constant is recomputed inside the call - hoisted out of a layer loop they
   //  would stay live across all bodies and push the 245-251 VGPR ones into spilling)
   asm volatile("" : "+v"(tid_));
   const int tid = tid_, lane = tid & 63, h = lane >> 5;
@@ -955,17 +955,6 @@ static inline size_t sep2_smem_bytes(const SepP& p) {
   X(33, 2, 0, 1) X(39, 2, 0, 1) X(51, 2, 0, 2) X(51, 4, 0, 2) X(63, 4, 0, 2) X(75, 4, 0, 2) \
   X(33, 2, 2, 1) X(39, 2, 2, 1) X(51, 4, 2, 2) X(51, 4, 4, 2) X(63, 4, 4, 2) X(75, 4, 4, 2) \
   X(0, 4, 0, 4)
-
-// position of (taps, groups, residual groups, passes) in SEP2_INSTANCES, -1: none (the persistent kernel's switch value)
-constexpr int sep2_shape_index(int K, int NG, int NGP, int NP) {
-  int i = 0;
-#define SEP2_IDX(K_, NG_, NGP_, NP_) \
-  if (K == K_ && NG == NG_ && NGP == NGP_ && NP == NP_) return i; \
-  ++i;
-  SEP2_INSTANCES(SEP2_IDX)
-#undef SEP2_IDX
-  return -1;
-}
 
 // Shapes k_sep2 is built for; everything else stays on k_sep.
 static inline bool sep2_shape_ok(const SepP& p) {
